@@ -1,0 +1,165 @@
+"""ctypes mirror of include/fleet_hip.h (struct layouts, constants) and the libfleet_hip.so loader.
+
+There is deliberately NO CPU fallback: if the HIP library is missing or no GPU is visible, every
+product entry point raises (`FleetHipError`).  The CPU restatement under oracle/ is test
+infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
+DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
+PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
+ACT_F32, ACT_F64 = 0, 1
+
+DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END = 1, 2, 4, 8, 16
+
+# fleet_get fields: name -> (id, dtype, per_car)
+FIELDS = {
+    "soc": (0, np.float64, True),
+    "hours_left": (1, np.float32, True),
+    "soh": (2, np.float64, True),
+    "soc_deg": (3, np.float64, True),
+    "target_soc": (4, np.float64, True),
+    "time_idx": (5, np.int32, False),
+    "start_idx": (6, np.int32, False),
+    "cashflow": (7, np.float64, False),
+    "ep_return": (8, np.float64, False),
+    "ep_len": (9, np.int32, False),
+    "last_ep_return": (10, np.float64, False),
+    "last_ep_len": (11, np.int32, False),
+    "rf_len": (12, np.int32, True),
+    "fd_cyc": (13, np.float64, True),
+    "fd_cal": (14, np.float64, True),
+    "sei_l": (15, np.float64, True),
+    "error_bits": (16, np.uint32, False),
+    "done": (17, np.uint8, False),
+    "episodes": (18, np.int32, False),
+    "penalty_record": (19, np.float64, False),
+}
+
+_I32_FIELDS = (
+    "abi_version", "struct_bytes", "num_envs", "num_cars", "table_rows", "episode_steps", "price_lookahead",
+    "bl_pv_lookahead", "steps_per_hour", "hour_phase", "include_building", "include_pv", "aux", "normalize",
+    "is_caretaker", "deg_mode", "picker_mode", "start_lo", "start_hi", "auto_reset", "env_id_offset", "reserved0",
+)
+_F64_FIELDS = (
+    "dt", "evse_power", "obc_max_power", "batt_cap_nominal", "init_battery_cap", "grid_connection",
+    "charging_eff", "discharging_eff", "fixed_markup", "variable_multiplier", "feed_in_deduction",
+    "price_multiplier", "penalty_invalid_action", "penalty_overcharging", "clip_overcharging",
+    "penalty_overloading", "fully_charged_reward", "target_soc", "target_soc_lunch", "eps", "def_soc",
+    "min_laxity", "init_soh", "temperature", "max_time_left", "max_price", "min_price", "max_tariff",
+    "min_tariff", "max_building", "max_pv", "max_soc", "max_hours_needed", "max_laxity", "max_evse", "max_grid",
+)
+
+
+class FleetParams(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in _I32_FIELDS] + [("seed", C.c_uint64)] + [(n, C.c_double) for n in _F64_FIELDS])
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_TABLE_FIELDS = (
+    ("there", C.POINTER(C.c_uint8)), ("time_left", C.POINTER(C.c_float)), ("soc_on_return", C.POINTER(C.c_double)),
+    ("delu", C.POINTER(C.c_double)), ("tariff", C.POINTER(C.c_double)), ("prc", C.POINTER(C.c_double)),
+    ("trc", C.POINTER(C.c_double)), ("load", C.POINTER(C.c_double)), ("pv", C.POINTER(C.c_double)),
+    ("hour", C.POINTER(C.c_uint8)), ("minute", C.POINTER(C.c_uint8)), ("month", C.POINTER(C.c_uint8)),
+    ("weekday", C.POINTER(C.c_uint8)), ("time_feat", C.POINTER(C.c_float)),
+)
+
+
+class FleetTablesC(C.Structure):
+    _fields_ = list(_TABLE_FIELDS)
+
+
+def pack_tables(tables, time_feat: np.ndarray | None):
+    """Returns (FleetTablesC, keepalive list).  Arrays are made contiguous with the ABI's dtypes."""
+    keep = []
+
+    def ptr(a, dtype, ctype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ctype))
+
+    t = FleetTablesC()
+    t.there = ptr(tables.there, np.uint8, C.c_uint8)
+    t.time_left = ptr(tables.time_left, np.float32, C.c_float)
+    t.soc_on_return = ptr(tables.soc_on_return, np.float64, C.c_double)
+    for name in ("delu", "tariff", "prc", "trc", "load", "pv"):
+        setattr(t, name, ptr(np.nan_to_num(getattr(tables, name), nan=0.0), np.float64, C.c_double))
+    for name in ("hour", "minute", "month", "weekday"):
+        setattr(t, name, ptr(getattr(tables, name), np.uint8, C.c_uint8))
+    if time_feat is not None:
+        t.time_feat = ptr(time_feat, np.float32, C.c_float)
+    else:
+        t.time_feat = C.POINTER(C.c_float)()
+    return t, keep
+
+
+class FleetHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"fleet_hip status {status}: {message}")
+        self.status = status
+
+
+_LIB = None
+LIB_NAME = "libfleet_hip.so"
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load_library():
+    """Load the in-tree HIP library; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.isfile(path):
+        raise FleetHipError(ERR_NODEVICE, f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32p, u8p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p
+    lib.fleet_obs_dim.argtypes = [C.POINTER(FleetParams)]
+    lib.fleet_obs_dim.restype = C.c_int
+    lib.fleet_create.argtypes = [C.POINTER(FleetParams), C.POINTER(FleetTablesC), C.c_int, C.POINTER(vp)]
+    lib.fleet_destroy.argtypes = [vp]
+    lib.fleet_last_error.argtypes = [vp]
+    lib.fleet_last_error.restype = C.c_char_p
+    lib.fleet_set_stream.argtypes = [vp, vp]
+    lib.fleet_synchronize.argtypes = [vp]
+    lib.fleet_set_start_schedule.argtypes = [vp, vp, C.c_int]
+    lib.fleet_reset_dev.argtypes = [vp, u8p, f32p]
+    lib.fleet_step_dev.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
+    lib.fleet_step_many_dev.argtypes = [vp, C.c_int, vp, C.c_int, f32p, f64p, vp]
+    lib.fleet_reset_host.argtypes = [vp, u8p, f32p]
+    lib.fleet_step_host.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
+    lib.fleet_get.argtypes = [vp, C.c_int, vp]
+    lib.fleet_get_dist_factor.argtypes = [vp, vp]
+    lib.fleet_check_errors.argtypes = [vp]
+    lib.fleet_timer_start.argtypes = [vp]
+    lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
+    for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_synchronize", "fleet_set_start_schedule",
+                 "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_reset_host", "fleet_step_host",
+                 "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start", "fleet_timer_stop",
+                 "fleet_run_tape_dev"):
+        getattr(lib, name).restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_synchronize",
+    "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_reset_host",
+    "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
+    "fleet_timer_stop", "fleet_run_tape_dev",
+)

@@ -1,0 +1,217 @@
+/*
+ * fleet_hip.h -- C ABI of the MI355X-native batched FleetRL step ("libfleet_hip.so").
+ *
+ * Drop-in boundary.  The reference has no native code; what this ABI replaces is the
+ * Python object protocol of `fleetrl.fleet_env.fleet_environment.FleetEnv`
+ *   __init__  /root/reference/fleetrl/fleet_env/fleet_environment.py:76-328
+ *   reset     :330-434
+ *   step      :436-702
+ *   getters   :741-799
+ * batched over `num_envs` independent environments (what SB3's SubprocVecEnv does with one OS process per
+ * env).  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every entry point returns an int status (FLEET_OK = 0); nothing throws, nothing aborts;
+ *     `fleet_last_error(h)` returns a human-readable message for the last non-zero status.
+ *   - plain pointers and sizes only; buffers are caller-owned.  `*_host` entry points take host
+ *     pointers and are synchronous; `*_dev` entry points take device pointers (e.g. torch-ROCm tensor
+ *     data_ptr()) and are asynchronous on the handle's HIP stream.
+ *   - one handle = one device + one stream; calls on one handle must be serialised by the caller.
+ *   - layouts are row-major:  actions [E,N], obs [E,obs_dim] f32, reward [E] f64, done [E] u8.
+ */
+#ifndef FLEET_HIP_H
+#define FLEET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLEET_ABI_VERSION 1
+
+/* status codes */
+#define FLEET_OK 0
+#define FLEET_ERR_INVALID 1   /* bad argument / unsupported configuration (SURVEY.md Q4 matrix)            */
+#define FLEET_ERR_HIP 2       /* a HIP runtime call failed                                               */
+#define FLEET_ERR_STATE 3     /* device-side error word set (impossible state, rainflow stack overflow)  */
+#define FLEET_ERR_NODEVICE 4  /* no HIP device: this library has no CPU fallback by design              */
+
+/* FleetParams.deg_mode -- which battery-degradation model runs on the daily 14:45 step                   */
+#define FLEET_DEG_NONE 0      /* calculate_degradation = False                                           */
+#define FLEET_DEG_LINEAR 1    /* EmpiricalDegradation  (utils/battery_degradation/empirical_degradation.py:29-99), quirk Q1 */
+#define FLEET_DEG_RAINFLOW 2  /* RainflowSeiDegradation (rainflow_sei_degradation.py:91-212)            */
+
+/* FleetParams.picker_mode -- episode start row (utils/time_picker/)                                      */
+#define FLEET_PICK_STATIC 0   /* always start_lo                                                         */
+#define FLEET_PICK_RANDOM 1   /* uniform integer in [start_lo, start_hi], counter-based Philox4x32-10   */
+#define FLEET_PICK_EVAL 2     /* same sampler, caller passes the validation range                       */
+
+/* action element type */
+#define FLEET_ACT_F32 0
+#define FLEET_ACT_F64 1
+
+/* device-side error bits (per env, OR-ed into one word; see fleet_get(FLEET_F_ERROR_BITS))               */
+#define FLEET_DEVERR_OBS_FORMAT 1u     /* the reference's `raise TypeError("Observation format not recognized")` :610 */
+#define FLEET_DEVERR_NEG_LIFE 2u       /* "Life degradation is negative" rainflow_sei_degradation.py:179-180         */
+#define FLEET_DEVERR_SOH_MISMATCH 4u   /* "Degradation calculation is not correct" :209-210                         */
+#define FLEET_DEVERR_DOD_RANGE 8u      /* "DoD too large" :164-167                                                   */
+#define FLEET_DEVERR_TABLE_END 16u     /* episode ran past the last table row                                        */
+
+/*
+ * Scalars of one env group (all envs of a handle share tables and parameters).
+ * Field meaning follows the reference's config classes; see fleetrl_amd/config.py for how each is
+ * derived from the reference's config dict.
+ */
+typedef struct FleetParams {
+  int32_t abi_version;      /* FLEET_ABI_VERSION */
+  int32_t struct_bytes;     /* sizeof(FleetParams) as seen by the caller */
+  int32_t num_envs;         /* E */
+  int32_t num_cars;         /* N  (db["ID"].max()+1, fleet_environment.py:260) */
+  int32_t table_rows;       /* T */
+  int32_t episode_steps;    /* episode_length[h] * steps_per_hour; finish = start + episode_steps (:355) */
+  int32_t price_lookahead;  /* L  (time_config.py:14) */
+  int32_t bl_pv_lookahead;  /* B  (time_config.py:15) */
+  int32_t steps_per_hour;   /* 60 / minutes */
+  int32_t hour_phase;       /* table row 0 lies `hour_phase` steps after a full clock hour (0 for shipped data) */
+  int32_t include_building; /* flags, fleet_environment.py:139-145 */
+  int32_t include_pv;
+  int32_t aux;
+  int32_t normalize;        /* normalize_in_env -> OracleNormalization, else UnitNormalization */
+  int32_t is_caretaker;     /* CompanyType.Caretaker: lunch-break target SOC (:536-554) */
+  int32_t deg_mode;         /* FLEET_DEG_* */
+  int32_t picker_mode;      /* FLEET_PICK_* */
+  int32_t start_lo;         /* inclusive */
+  int32_t start_hi;         /* inclusive */
+  int32_t auto_reset;       /* 1: VecEnv semantics (done envs are reset inside the step, terminal obs reported)
+                               0: gymnasium.Env semantics (obs of a done env is its terminal obs)           */
+  int32_t env_id_offset;    /* global index of env 0 of this handle (multi-GPU sharding keeps RNG streams env-stable) */
+  int32_t reserved0;
+  uint64_t seed;            /* Philox key for the random/eval picker */
+
+  double dt;                /* hours per step (time_config.py:24) */
+  double evse_power;        /* load_calculation.evse_max_power */
+  double obc_max_power;     /* ev_config.obc_max_power; possible_power = min(obc, evse) (ev_charger.py:95) */
+  double batt_cap_nominal;  /* load_calculation.batt_cap, used by the aux observations only (observer_*.py:88) */
+  double init_battery_cap;  /* ev_config.init_battery_cap */
+  double grid_connection;   /* load_calculation.grid_connection */
+  double charging_eff;
+  double discharging_eff;
+  double fixed_markup;      /* EUR/MWh (obs) ; spot_offset = fixed_markup/1000 (ev_charger.py:34) */
+  double variable_multiplier;
+  double feed_in_deduction;
+  double price_multiplier;  /* already scaled by max_batt_cap/init_cap (:194-195) and zeroed by ignore_price_reward */
+  double penalty_invalid_action;
+  double penalty_overcharging;
+  double clip_overcharging;
+  double penalty_overloading;
+  double fully_charged_reward;
+  double target_soc;
+  double target_soc_lunch;
+  double eps;               /* 0.005 (:230) */
+  double def_soc;
+  double min_laxity;
+  double init_soh;
+  double temperature;
+  /* OracleNormalization.__init__ constants (oracle_normalization.py:34-54); ignored unless `normalize` */
+  double max_time_left;
+  double max_price, min_price;
+  double max_tariff, min_tariff;
+  double max_building;
+  double max_pv;
+  double max_soc;
+  double max_hours_needed;
+  double max_laxity;
+  double max_evse;
+  double max_grid;
+} FleetParams;
+
+/* Pre-staged tables (HOST pointers; fleet_create uploads / re-packs them).  Row t, EV c -> [t*N + c].     */
+typedef struct FleetTables {
+  const uint8_t* there;         /* [T,N]  db["There"]                          */
+  const float* time_left;       /* [T,N]  db["time_left"], multiples of dt     */
+  const double* soc_on_return;  /* [T,N]  db["SOC_on_return"]                  */
+  const double* delu;           /* [T]    EUR/MWh                              */
+  const double* tariff;         /* [T]                                         */
+  const double* prc;            /* [T]    price_reward_curve                   */
+  const double* trc;            /* [T]    tariff_reward_curve                  */
+  const double* load;           /* [T]    kW (zeros if !include_building)      */
+  const double* pv;             /* [T]    kW (zeros if !include_pv)            */
+  const uint8_t* hour;          /* [T]                                         */
+  const uint8_t* minute;        /* [T]                                         */
+  const uint8_t* month;         /* [T]  1..12                                  */
+  const uint8_t* weekday;       /* [T]  Monday = 0                             */
+  const float* time_feat;       /* [T,6] month/week/hour sin,cos as float32, or NULL (library computes with libm) */
+} FleetTables;
+
+typedef struct FleetEnvBatch* fleet_handle;
+
+/* fields for fleet_get (all copied to a HOST buffer) */
+#define FLEET_F_SOC 0            /* f64 [E,N] */
+#define FLEET_F_HOURS_LEFT 1     /* f32 [E,N] */
+#define FLEET_F_SOH 2            /* f64 [E,N] */
+#define FLEET_F_SOC_DEG 3        /* f64 [E,N] */
+#define FLEET_F_TARGET_SOC 4     /* f64 [E,N] */
+#define FLEET_F_TIME_IDX 5       /* i32 [E]   */
+#define FLEET_F_START_IDX 6      /* i32 [E]   */
+#define FLEET_F_CASHFLOW 7       /* f64 [E]   last step's cashflow (episode.current_charging_expense) */
+#define FLEET_F_EP_RETURN 8      /* f64 [E]   running episode return (episode.cumulative_reward)      */
+#define FLEET_F_EP_LEN 9         /* i32 [E]   */
+#define FLEET_F_LAST_EP_RETURN 10 /* f64 [E]  return of the last finished episode */
+#define FLEET_F_LAST_EP_LEN 11   /* i32 [E]   */
+#define FLEET_F_RF_LEN 12        /* i32 [E,N] sei_deg.rainflow_length */
+#define FLEET_F_FD_CYC 13        /* f64 [E,N] */
+#define FLEET_F_FD_CAL 14        /* f64 [E,N] */
+#define FLEET_F_SEI_L 15         /* f64 [E,N] */
+#define FLEET_F_ERROR_BITS 16    /* u32 [E]   */
+#define FLEET_F_DONE 17          /* u8  [E]   episode.done */
+#define FLEET_F_EPISODES 18      /* i32 [E]   finished-episode counter */
+#define FLEET_F_PENALTY_RECORD 19 /* f64 [E]  episode.penalty_record */
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */
+int fleet_create(const FleetParams* p, const FleetTables* t, int device, fleet_handle* out);
+int fleet_destroy(fleet_handle h);
+const char* fleet_last_error(fleet_handle h);  /* h may be NULL: error of the last failed fleet_create */
+int fleet_set_stream(fleet_handle h, void* hip_stream);  /* adopt an external hipStream_t (e.g. torch's) */
+int fleet_synchronize(fleet_handle h);
+
+/* Inject episode start rows (parity tests / `set_start_time`): `starts` is HOST [n_episodes,E]; episode k of
+ * env e starts at starts[(k % n_episodes)*E + e].  n_episodes = 0 clears the schedule (picker resumes). */
+int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episodes);
+
+/* ---- reset / step, device pointers, asynchronous on the handle's stream --------------------------------
+ * mask: u8 [E] or NULL (= all).  obs: f32 [E,obs_dim] (rows of unmasked envs are left untouched).        */
+int fleet_reset_dev(fleet_handle h, const uint8_t* mask, float* obs);
+int fleet_step_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
+                   uint8_t* done, float* terminal_obs /* [E,obs_dim] or NULL */);
+/* K consecutive steps in ONE launch for open-loop rollouts (actions known up front): actions [K,E,N];
+ * obs = observation after the last step, reward_sum[E] = sum of the K rewards, done_count[E] = number of
+ * episode ends among them.  auto_reset must be 1. */
+int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtype, float* obs,
+                        double* reward_sum, int32_t* done_count);
+
+/* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
+int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);
+int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
+                    uint8_t* done, float* terminal_obs);
+
+/* ---- state access ------------------------------------------------------------------------------------- */
+int fleet_get(fleet_handle h, int field, void* out_host);
+/* `FleetEnv.get_dist_factor` (:782-799): hours_needed / (hours_left + 0.001) from a fresh observation, f64 [E,N] */
+int fleet_get_dist_factor(fleet_handle h, double* out_host);
+/* raise FLEET_ERR_STATE if any env has device error bits set */
+int fleet_check_errors(fleet_handle h);
+
+/* ---- measurement helpers (bench.py): HIP events on the handle's stream ------------------------------- */
+int fleet_timer_start(fleet_handle h);
+int fleet_timer_stop(fleet_handle h, float* elapsed_ms);  /* synchronises on the stop event */
+/* launch `steps` single-step launches back to back from a device-resident action tape [tape_len,E,N]
+ * (step i uses tape row i % tape_len); optionally through a captured hipGraph. */
+int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
+                       float* obs, double* reward, uint8_t* done, int use_graph);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEET_HIP_H */

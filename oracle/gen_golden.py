@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference):   python oracle/gen_golden.py [name ...]
+
+For every configuration below it builds `E` independent reference `FleetEnv` objects, drives each through
+`episodes` consecutive episodes with seeded float32-valued actions (fed to the reference as float64 copies,
+SURVEY.md section 7 "NumPy-version trap"), emulating SB3's vec-env auto-reset (on done: keep the terminal
+observation, call reset(), continue with the reset observation), and records everything the parity tests
+compare:
+
+  per step : obs f32, reward, done, cashflow, soc, hours_left, soh, soc_deg, target_soc, time row
+  per reset: reset obs
+  at the end of every episode: the persistent degradation state (rainflow_length, fd_cyc, fd_cal, l)
+  tables   : the reference's own `db` columns, cut to the rows the episodes touch (plus look-ahead)
+  scalars  : grid connection, EVSE power, battery sizes, scaled price multiplier, normaliser constants, obs_dim
+
+Episode start rows are injected (the reference's pickers use unseeded `random`, quirk Q12).
+The fixture is data only: no reference source text is stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_harness import make_ref_env, set_static_start, stacked_inputs_dir  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (config overrides, n_evs (0 = shipped single-EV file), E, episodes, action mode)
+CONFIGS = {
+    # BASELINE C1 family: 1 env x 1 EV, lmd, price-only obs, linear degradation (quirk Q1 shim), 24 h
+    "lmd1_price_linear": (dict(use_case="lmd", schedule_name="lmd_sched_single.csv", include_building=False,
+                               include_pv=False, calculate_degradation=True, deg_emp=True, episode_length=24), 0, 2, 3, "wide"),
+    # BASELINE C2 family: 5 EVs, lmd, price-only obs, linear degradation, 48 h
+    "lmd5_price_linear": (dict(use_case="lmd", include_building=False, include_pv=False,
+                               calculate_degradation=True, deg_emp=True, episode_length=48), 5, 3, 2, "charge"),
+    # BASELINE C3 family: ct, load+pv obs, rainflow/SEI degradation, 48 h, 4 episodes (cross-episode state, quirk Q6)
+    "ct5_both_rainflow": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                               calculate_degradation=True, deg_emp=False, episode_length=48), 5, 3, 4, "charge"),
+    # BASELINE C4 family: ut, load+pv, normalised observations, rainflow, 48 h
+    "ut3_both_norm_rainflow": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
+                                    normalize_in_env=True, calculate_degradation=True, deg_emp=False,
+                                    episode_length=48), 3, 2, 2, "wide"),
+    # remaining observer variants
+    "lmd2_building_norm_noaux": (dict(use_case="lmd", building_name="load_lmd.csv", include_building=True,
+                                      include_pv=False, normalize_in_env=True, aux=False,
+                                      calculate_degradation=False, episode_length=24), 2, 2, 2, "wide"),
+    "ct2_pv_nodeg": (dict(use_case="ct", building_name="load_ct.csv", include_building=False, include_pv=True,
+                          calculate_degradation=False, episode_length=24), 2, 2, 2, "charge"),
+    # small grid connection so that the overload penalty fires; custom use case
+    "custom3_both_overload": (dict(use_case="custom", building_name="load_lmd.csv", include_building=True,
+                                   include_pv=True, calculate_degradation=True, deg_emp=False, episode_length=24,
+                                   custom_ev_charger_power_in_kw=22, custom_ev_battery_size_in_kwh=40,
+                                   custom_grid_connection_in_kw=200, init_battery_cap=40, obc_max_power=11,
+                                   max_batt_cap_in_all_use_cases=60), 3, 2, 2, "full"),
+}
+
+
+def make_actions(rng: np.random.Generator, steps: int, n: int, mode: str) -> np.ndarray:
+    if mode == "wide":
+        a = rng.uniform(-1, 1, size=(steps, n))
+    elif mode == "charge":
+        a = rng.uniform(-0.3, 1, size=(steps, n))
+    else:  # "full": mostly hard charging so that the grid connection overloads
+        a = rng.uniform(0.4, 1, size=(steps, n))
+        a[rng.random((steps, n)) < 0.1] = -1.0
+    a[rng.random((steps, n)) < 0.15] = 0.0
+    a[rng.random((steps, n)) < 0.03] = 1.0
+    return a.astype(np.float32)
+
+
+def run_config(name: str):
+    ov, n_evs, E, episodes, mode = CONFIGS[name]
+    ov = dict(ov)
+    uc = ov["use_case"]
+    if n_evs:
+        sched_uc = "lmd" if uc == "custom" else uc
+        dp, sched = stacked_inputs_dir(sched_uc, n_evs)
+        ov.update(data_path=dp, schedule_name=sched)
+    ov.setdefault("target_soc", 0.85)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    ep_steps = ov["episode_length"] * 4
+    total = ep_steps * episodes
+    rec = None
+    starts = np.zeros((episodes, E), dtype=np.int32)
+    t0 = time.time()
+    db0 = None
+    scalars = {}
+    for e in range(E):
+        env = make_ref_env(ov)
+        N = int(env.num_cars)
+        T = len(env.db) // N
+        if rec is None:
+            D = env.observation_space.shape[0]
+            rec = dict(
+                actions=np.zeros((E, total, N), np.float32), obs=np.zeros((E, total, D), np.float32),
+                terminal_obs=np.zeros((E, episodes, D), np.float32), reset_obs=np.zeros((E, episodes, D), np.float32),
+                reward=np.zeros((E, total)), done=np.zeros((E, total), np.uint8), cashflow=np.zeros((E, total)),
+                soc=np.zeros((E, total, N)), hours_left=np.zeros((E, total, N)), soh=np.zeros((E, total, N)),
+                soc_deg=np.zeros((E, total, N)), target_soc=np.zeros((E, total, N)), time_idx=np.zeros((E, total), np.int32),
+                rf_len=np.zeros((E, episodes, N), np.int32), fd_cyc=np.zeros((E, episodes, N)),
+                fd_cal=np.zeros((E, episodes, N)), sei_l=np.zeros((E, episodes, N)),
+                reset_soc=np.zeros((E, episodes, N)), reset_hours_left=np.zeros((E, episodes, N)),
+                dist_factor=np.zeros((E, episodes, N)),
+            )
+            db0 = env.db
+            lc = env.load_calculation
+            scalars = dict(
+                grid_connection=lc.grid_connection, evse_power=lc.evse_max_power, batt_cap_nominal=lc.batt_cap,
+                init_battery_cap=env.ev_config.init_battery_cap, price_multiplier=env.score_config.price_multiplier,
+                obs_dim=D, num_cars=N, table_rows_full=T,
+                obs_low=float(env.observation_space.low.min()), obs_high=float(env.observation_space.high.max()),
+            )
+            if ov.get("normalize_in_env"):
+                nz = env.normalizer
+                for k in ("max_time_left", "max_price", "min_price", "max_tariff", "min_tariff"):
+                    scalars[k] = float(getattr(nz, k))
+                if nz.building_flag:
+                    scalars["max_building"] = float(nz.max_building)
+                if nz.pv_flag:
+                    scalars["max_pv"] = float(nz.max_pv)
+                if nz.aux:
+                    scalars["max_hours_needed"] = float(nz.max_hours_needed)
+        dates0 = env.db["date"].values[:T]
+        acts = make_actions(rng, total, N, mode)
+        rec["actions"][e] = acts
+        # start rows: anywhere in the training range, plus a forced 14:30 start (degradation on the very first step)
+        # (kept inside one 45-day span per configuration so that the stored table window stays small)
+        if e == 0:
+            span0 = int(rng.integers(0, T - 1 - 60 * 96 - 45 * 96))
+        cand = rng.integers(span0, span0 + 45 * 96, size=episodes)
+        if e == 0 and episodes > 1:
+            cand[1] = (cand[1] // 96) * 96 + 58
+        starts[:, e] = cand
+        k = 0
+        for ep in range(episodes):
+            set_static_start(env, int(starts[ep, e]))
+            obs, _ = env.reset()
+            rec["reset_obs"][e, ep] = obs
+            rec["reset_soc"][e, ep] = np.asarray(env.episode.soc, dtype=np.float64)
+            rec["reset_hours_left"][e, ep] = np.asarray(env.episode.hours_left, dtype=np.float64)
+            if ov.get("aux", True):
+                rec["dist_factor"][e, ep] = np.asarray(env.get_dist_factor(), dtype=np.float64)
+            for _ in range(ep_steps):
+                a64 = acts[k].astype(np.float64)
+                obs, r, d, _tr, _info = env.step(a64)
+                rec["obs"][e, k] = obs
+                rec["reward"][e, k] = r
+                rec["done"][e, k] = d
+                rec["cashflow"][e, k] = env.episode.current_charging_expense
+                rec["soc"][e, k] = np.asarray(env.episode.soc, dtype=np.float64)
+                rec["hours_left"][e, k] = np.asarray(env.episode.hours_left, dtype=np.float64)
+                rec["soh"][e, k] = np.asarray(env.episode.soh, dtype=np.float64)
+                rec["soc_deg"][e, k] = np.asarray(env.episode.soc_deg, dtype=np.float64)
+                rec["target_soc"][e, k] = np.asarray(env.target_soc, dtype=np.float64)
+                rec["time_idx"][e, k] = int(np.searchsorted(dates0, np.datetime64(env.episode.time)))
+                k += 1
+            assert d, "episode must end exactly after episode_length hours"
+            rec["terminal_obs"][e, ep] = obs
+            if ov["calculate_degradation"] and not ov["deg_emp"]:
+                sd = env.sei_deg
+                rec["rf_len"][e, ep] = sd.rainflow_length
+                rec["fd_cyc"][e, ep] = sd.fd_cyc
+                rec["fd_cal"][e, ep] = sd.fd_cal
+                rec["sei_l"][e, ep] = sd.l
+        print(f"  {name}: env {e + 1}/{E} done ({time.time() - t0:.0f}s)", flush=True)
+
+    # ---- tables: the reference's db columns for the rows the episodes touch --------------------------------
+    N = scalars["num_cars"]
+    T = scalars["table_rows_full"]
+    L2 = (ov.get("price_lookahead", 8) + 2) * 4 + 1
+    w0 = (int(starts.min()) // 96) * 96
+    w1 = min(T, int(starts.max()) + ep_steps + L2 + 1)
+    col = lambda c: db0[c].values.reshape(N, T).T[w0:w1]  # noqa: E731
+    dates = db0["date"].values[:T][w0:w1].astype("datetime64[s]")
+    tables = dict(
+        dates=dates.astype(np.int64), there=col("There").astype(np.uint8), time_left=col("time_left").astype(np.float64),
+        soc_on_return=col("SOC_on_return").astype(np.float64),
+        delu=db0["DELU"].values[:T][w0:w1], tariff=db0["tariff"].values[:T][w0:w1],
+        prc=db0["price_reward_curve"].values[:T][w0:w1], trc=db0["tariff_reward_curve"].values[:T][w0:w1],
+    )
+    tables["load"] = db0["load"].values[:T][w0:w1] if "load" in db0 else np.zeros(w1 - w0)
+    tables["pv"] = db0["pv"].values[:T][w0:w1] if "pv" in db0 else np.zeros(w1 - w0)
+    # whole-table extrema the normaliser / grid sizing need (the window alone cannot give them)
+    ext = dict(max_time_left=float(np.nanmax(db0["time_left"].values)), max_delu=float(np.nanmax(db0["DELU"].values)),
+               min_delu=float(np.nanmin(db0["DELU"].values)), max_tariff=float(np.nanmax(db0["tariff"].values)),
+               min_tariff=float(np.nanmin(db0["tariff"].values)),
+               max_load=float(np.nanmax(db0["load"].values)) if "load" in db0 else 0.0,
+               max_pv=float(np.nanmax(db0["pv"].values)) if "pv" in db0 else 0.0)
+    scalars.update({f"ext_{k}": v for k, v in ext.items()})
+    scalars["window_row0"] = w0
+
+    import json
+
+    from oracle.ref_harness import base_config
+
+    full_cfg = base_config()
+    full_cfg.update(ov)
+    full_cfg["data_path"] = "<not shipped>"
+    out = {f"tab_{k}": v for k, v in tables.items()}
+    out.update({f"sc_{k}": np.asarray(v) for k, v in scalars.items()})
+    out["cfg_json"] = np.asarray(json.dumps(full_cfg))
+    out.update(rec)
+    out["starts"] = starts - w0  # re-based to the window
+    out["time_idx"] = rec["time_idx"] - w0
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, f"trace_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), window rows [{w0},{w1})", flush=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CONFIGS)
+    for n in names:
+        run_config(n)

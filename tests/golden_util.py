@@ -1,0 +1,119 @@
+"""Shared helpers for the parity tests: load a committed golden trace (tests/golden/trace_*.npz, produced from
+the unmodified reference by oracle/gen_golden.py) and replay it on an engine.
+
+An "engine" is anything with reset() / step(actions) / get(name) / set_start_schedule(starts) -- the CPU oracle
+(oracle.fleet_oracle.OracleBatch) or the HIP product (fleetrl_amd.batch.FleetBatch).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+
+from fleetrl_amd.config import resolve_config
+from fleetrl_amd.params import make_params, time_features
+from fleetrl_amd.prestage import FleetTables
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRACE_NAMES = sorted(os.path.basename(p)[len("trace_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN_DIR, "trace_*.npz")))
+
+
+def load_trace(name: str) -> SimpleNamespace:
+    z = np.load(os.path.join(GOLDEN_DIR, f"trace_{name}.npz"), allow_pickle=False)
+    g = SimpleNamespace(**{k: z[k] for k in z.files})
+    g.name = name
+    g.cfg = json.loads(str(z["cfg_json"]))
+    g.rc = resolve_config(g.cfg)
+    dates = z["tab_dates"].astype("datetime64[s]")
+    day = dates.astype("datetime64[D]")
+    hours = ((dates - day) // np.timedelta64(3600, "s")).astype(np.int64)
+    minute = ((dates - dates.astype("datetime64[h]")) // np.timedelta64(60, "s")).astype(np.int64)
+    month = dates.astype("datetime64[M]").astype(np.int64) % 12 + 1
+    weekday = (day.astype(np.int64) + 3) % 7
+    g.tables = FleetTables(
+        dates=dates, there=z["tab_there"], time_left=z["tab_time_left"].astype(np.float32),
+        soc_on_return=z["tab_soc_on_return"], consumption=np.zeros_like(z["tab_soc_on_return"]),
+        delu=z["tab_delu"], tariff=z["tab_tariff"], prc=z["tab_prc"], trc=z["tab_trc"], load=z["tab_load"], pv=z["tab_pv"],
+        hour=hours.astype(np.uint8), minute=minute.astype(np.uint8), month=month.astype(np.uint8),
+        weekday=weekday.astype(np.uint8), minutes_per_step=g.rc.minutes,
+    )
+    g.extrema = {k[len("sc_ext_"):]: float(z[k]) for k in z.files if k.startswith("sc_ext_")}
+    g.E, g.total, g.N = g.actions.shape
+    g.episodes = g.starts.shape[0]
+    g.ep_steps = g.total // g.episodes
+    g.time_feat = time_features(g.tables)
+    return g
+
+
+def params_for(g, num_envs=None, auto_reset=True):
+    return make_params(g.rc, g.tables, g.E if num_envs is None else num_envs, auto_reset=auto_reset,
+                       extrema=g.extrema, start_range=(0, 0))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12))) if a.size else 0.0
+
+
+def replay(g, engine, *, float_rtol=1e-9, obs_exact=True, check_sei=True, env_map=None):
+    """Drive `engine` (E_engine envs) with the golden actions/starts; env i of the engine replays golden env
+    env_map[i] (default i % g.E).  Asserts bit-exact flags/indices, float32 obs (exact or 1e-5 rel), and
+    float64 state within `float_rtol` relative.  Returns the largest relative errors seen."""
+    Ee = engine.E
+    env_map = np.arange(Ee) % g.E if env_map is None else np.asarray(env_map)
+    engine.set_start_schedule(g.starts[:, env_map])
+    worst = dict(obs=0.0, reward=0.0, soc=0.0, soh=0.0, cashflow=0.0)
+    obs = engine.reset()
+    np.testing.assert_array_equal(engine.get("start_idx"), g.starts[0, env_map])
+
+    def cmp_obs(got, want, what):
+        if obs_exact:
+            np.testing.assert_array_equal(got, want, err_msg=what)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=what)
+        worst["obs"] = max(worst["obs"], rel_err(got, want))
+
+    cmp_obs(obs, g.reset_obs[env_map, 0], "reset obs, episode 0")
+    np.testing.assert_allclose(engine.get("soc"), g.reset_soc[env_map, 0], rtol=float_rtol, atol=0)
+    k = 0
+    for ep in range(g.episodes):
+        for s in range(g.ep_steps):
+            obs, rew, done, term = engine.step(g.actions[env_map, k])
+            last = s == g.ep_steps - 1
+            np.testing.assert_array_equal(done, g.done[env_map, k], err_msg=f"done flag, step {k}")
+            np.testing.assert_allclose(rew, g.reward[env_map, k], rtol=float_rtol, atol=1e-12, err_msg=f"reward, step {k}")
+            worst["reward"] = max(worst["reward"], rel_err(rew, g.reward[env_map, k]))
+            np.testing.assert_allclose(engine.get("cashflow"), g.cashflow[env_map, k], rtol=float_rtol, atol=1e-13,
+                                       err_msg=f"cashflow, step {k}")
+            if not last:
+                cmp_obs(obs, g.obs[env_map, k], f"obs, step {k}")
+                np.testing.assert_array_equal(engine.get("time_idx"), g.time_idx[env_map, k], err_msg=f"time row, step {k}")
+                np.testing.assert_array_equal(engine.get("hours_left").astype(np.float64), g.hours_left[env_map, k],
+                                              err_msg=f"hours_left, step {k}")
+                np.testing.assert_allclose(engine.get("soc"), g.soc[env_map, k], rtol=float_rtol, atol=1e-15, err_msg=f"soc, step {k}")
+                np.testing.assert_allclose(engine.get("soh"), g.soh[env_map, k], rtol=float_rtol, atol=0, err_msg=f"soh, step {k}")
+                np.testing.assert_allclose(engine.get("soc_deg"), g.soc_deg[env_map, k], rtol=float_rtol, atol=1e-15)
+                np.testing.assert_array_equal(engine.get("target_soc"), g.target_soc[env_map, k])
+                worst["soc"] = max(worst["soc"], rel_err(engine.get("soc"), g.soc[env_map, k]))
+                worst["soh"] = max(worst["soh"], rel_err(engine.get("soh"), g.soh[env_map, k]))
+            else:
+                # vec-env semantics: terminal observation is reported separately, obs is the next episode's reset obs
+                cmp_obs(term, g.terminal_obs[env_map, ep], f"terminal obs, episode {ep}")
+                if check_sei and g.rc.deg_mode == 2:
+                    np.testing.assert_array_equal(engine.get("rf_len"), g.rf_len[env_map, ep], err_msg=f"rainflow_length, episode {ep}")
+                    np.testing.assert_allclose(engine.get("fd_cyc"), g.fd_cyc[env_map, ep], rtol=1e-9, atol=1e-18)
+                    np.testing.assert_allclose(engine.get("fd_cal"), g.fd_cal[env_map, ep], rtol=1e-9, atol=1e-18)
+                    np.testing.assert_allclose(engine.get("sei_l"), g.sei_l[env_map, ep], rtol=1e-9, atol=1e-18)
+                if ep + 1 < g.episodes:
+                    cmp_obs(obs, g.reset_obs[env_map, ep + 1], f"reset obs, episode {ep + 1}")
+                    np.testing.assert_array_equal(engine.get("start_idx"), g.starts[ep + 1, env_map])
+                    np.testing.assert_allclose(engine.get("soc"), g.reset_soc[env_map, ep + 1], rtol=float_rtol, atol=0)
+                    if g.rc.aux:
+                        np.testing.assert_allclose(engine.dist_factor(), g.dist_factor[env_map, ep + 1], rtol=1e-12, atol=0)
+            k += 1
+    assert not np.any(engine.get("error_bits")), "device/oracle error bits set"
+    return worst
