@@ -1,0 +1,134 @@
+"""FleetBatch: thin, typed Python handle over the C ABI (include/fleet_hip.h, libfleet_hip.so).
+
+Two calling styles, same kernels:
+  * NumPy / host pointers (`reset`, `step`): synchronous, what a Gymnasium/SB3 caller sees;
+  * device pointers (`reset_dev`, `step_dev`, `step_many_dev`, `run_tape_dev`): torch-ROCm tensors stay in HBM,
+    launches are asynchronous on the handle's stream.
+No CPU fallback: constructing a FleetBatch without the HIP library or without a GPU raises FleetHipError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import FleetHipError
+
+__all__ = ["FleetBatch", "FleetHipError"]
+
+
+class FleetBatch:
+    def __init__(self, params: _capi.FleetParams, tables, time_feat: np.ndarray | None = None, device: int = 0):
+        self.lib = _capi.load_library()
+        self.params = params
+        tc, keep = _capi.pack_tables(tables, time_feat)
+        h = C.c_void_p()
+        rc = self.lib.fleet_create(C.byref(params), C.byref(tc), int(device), C.byref(h))
+        del keep  # fleet_create copied everything to the device
+        if rc != _capi.OK:
+            raise FleetHipError(rc, self.lib.fleet_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+        self.E, self.N = int(params.num_envs), int(params.num_cars)
+        self.obs_dim = int(self.lib.fleet_obs_dim(C.byref(params)))
+
+    # ------------------------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != _capi.OK:
+            raise FleetHipError(rc, self.lib.fleet_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fleet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self.lib.fleet_synchronize(self.h))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.lib.fleet_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_start_schedule(self, starts):
+        if starts is None:
+            self._check(self.lib.fleet_set_start_schedule(self.h, None, 0))
+            return
+        s = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, self.E)
+        self._check(self.lib.fleet_set_start_schedule(self.h, s.ctypes.data, s.shape[0]))
+
+    # ---- host (NumPy) path ---------------------------------------------------------------------------------
+    def reset(self, mask=None, out: np.ndarray | None = None) -> np.ndarray:
+        obs = out if out is not None else np.zeros((self.E, self.obs_dim), dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.lib.fleet_reset_host(self.h, None if m is None else m.ctypes.data, obs.ctypes.data))
+        return obs
+
+    @staticmethod
+    def _act(actions, shape):
+        a = np.asarray(actions)
+        if a.dtype == np.float64:
+            a = np.ascontiguousarray(a)
+            dt = _capi.ACT_F64
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            dt = _capi.ACT_F32
+        if a.shape != shape:
+            raise ValueError(f"actions must have shape {shape}, got {a.shape}")
+        return a, dt
+
+    def step(self, actions):
+        """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim])"""
+        a, dt = self._act(actions, (self.E, self.N))
+        obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
+        term = np.zeros((self.E, self.obs_dim), dtype=np.float32)
+        rew = np.empty(self.E)
+        done = np.empty(self.E, dtype=np.uint8)
+        self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,
+                                              done.ctypes.data, term.ctypes.data))
+        return obs, rew, done, term
+
+    # ---- device-pointer path (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) -------------------
+    def reset_dev(self, obs_ptr: int, mask_ptr: int | None = None):
+        self._check(self.lib.fleet_reset_dev(self.h, mask_ptr, obs_ptr))
+
+    def step_dev(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, terminal_ptr: int | None = None,
+                 act_dtype: int = _capi.ACT_F32):
+        self._check(self.lib.fleet_step_dev(self.h, actions_ptr, act_dtype, obs_ptr, reward_ptr, done_ptr, terminal_ptr))
+
+    def step_many_dev(self, K: int, actions_ptr: int, obs_ptr: int, reward_sum_ptr: int, done_count_ptr: int | None = None,
+                      act_dtype: int = _capi.ACT_F32):
+        self._check(self.lib.fleet_step_many_dev(self.h, int(K), actions_ptr, act_dtype, obs_ptr, reward_sum_ptr, done_count_ptr))
+
+    def run_tape_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
+                     use_graph: bool = True, act_dtype: int = _capi.ACT_F32):
+        self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
+                                                 reward_ptr, done_ptr, int(bool(use_graph))))
+
+    def timer_start(self):
+        self._check(self.lib.fleet_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.fleet_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- state access ----------------------------------------------------------------------------------------
+    def get(self, name: str) -> np.ndarray:
+        fid, dtype, per_car = _capi.FIELDS[name]
+        out = np.zeros((self.E, self.N) if per_car else (self.E,), dtype=dtype)
+        self._check(self.lib.fleet_get(self.h, fid, out.ctypes.data))
+        return out
+
+    def dist_factor(self) -> np.ndarray:
+        out = np.zeros((self.E, self.N))
+        self._check(self.lib.fleet_get_dist_factor(self.h, out.ctypes.data))
+        return out
+
+    def check_errors(self):
+        self._check(self.lib.fleet_check_errors(self.h))
