@@ -148,10 +148,11 @@ def load_library():
     lib.fleet_timer_start.argtypes = [vp]
     lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
+    lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_reset_host", "fleet_step_host",
                  "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start", "fleet_timer_stop",
-                 "fleet_run_tape_dev"):
+                 "fleet_run_tape_dev", "fleet_time_steps_dev"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -161,5 +162,5 @@ EXPORTED_SYMBOLS = (
     "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_synchronize",
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
-    "fleet_timer_stop", "fleet_run_tape_dev",
+    "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev",
 )

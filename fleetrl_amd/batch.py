@@ -110,6 +110,14 @@ class FleetBatch:
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
                                                  reward_ptr, done_ptr, int(bool(use_graph))))
 
+    def time_steps_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
+                       act_dtype: int = _capi.ACT_F32) -> np.ndarray:
+        """Per-launch device durations [ms] measured with one HIP event pair per launch on the handle's stream."""
+        ms = np.zeros(int(steps), dtype=np.float32)
+        self._check(self.lib.fleet_time_steps_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
+                                                   reward_ptr, done_ptr, ms.ctypes.data))
+        return ms
+
     def timer_start(self):
         self._check(self.lib.fleet_timer_start(self.h))
 

@@ -35,6 +35,9 @@ struct Batch {
   uint8_t* st_mask = nullptr;
   double* st_dist = nullptr;
   int32_t* dev_sched = nullptr;
+  FleetCold cold_host{};
+  FleetCold* cold_dev = nullptr;
+  void* st_field = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // cached tape graph
   hipGraphExec_t graph_exec = nullptr;
@@ -183,7 +186,7 @@ void build_tail_rows(const FleetParams& p, const FleetTables& t, int tail_a, int
 // Physics rows: only combinations the reference itself evaluates on per-time scalars, same float64 operations
 // in the same order, so the stored doubles are bit-identical to what the reference computes per step.
 void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<PhysRow>& phys, std::vector<uint8_t>& flags) {
-  const int T = p.table_rows;
+  const int T = p.table_rows, N = p.num_cars;
   phys.resize(T);
   flags.resize(T);
   const double spot_offset = p.fixed_markup / 1000;  // ev_charger.py:34
@@ -195,12 +198,47 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
     q.k_discharge = -1 * p.price_multiplier * t.trc[r] / 1000;    // :204-205
     q.load = p.include_building ? t.load[r] : 0.0;
     q.pv = p.include_pv ? t.pv[r] : 0.0;
-    q.pv_energy = p.include_pv ? t.pv[r] * p.dt : 0.0;            // :134-136
+    // connected_cars = max(sum(There[t]), 1) is a function of the time row alone (:138-140), so
+    // current_pv_energy / connected_cars (:134,142) can be tabulated with the reference's own two operations
+    long connected = 0;
+    for (int c = 0; c < N; ++c) connected += t.there[(size_t)r * N + c];
+    if (connected < 1) connected = 1;
+    const double pv_energy = p.include_pv ? t.pv[r] * p.dt : 0.0;
+    q.pv_share = pv_energy / (double)connected;
     q.reserved = 0.0;
     uint8_t f = 0;
     if (t.hour[r] == 14 && t.minute[r] == 45) f |= FLEET_TFLAG_DEG;
     if (t.hour[r] > 11 && t.hour[r] < 15) f |= FLEET_TFLAG_LUNCH;
     flags[r] = f;
+  }
+}
+
+// Per-(t, EV) records: the three schedule columns packed into 16 bytes, and the five auxiliary observation
+// slots pre-assembled for the configured target SOC (observer_bl_pv.py:85-91 and, when normalising,
+// oracle_normalization.py:127-131) -- float64 in the reference's operation order, stored as the float32 words the
+// reference would emit.  `there` is kept in TabRec; the other four go to AuxRec.
+void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabRec>& tab, std::vector<AuxRec>& aux) {
+  const size_t TN = (size_t)p.table_rows * p.num_cars;
+  tab.resize(TN);
+  if (p.aux) aux.resize(TN);
+  const bool norm = p.normalize != 0;
+  const double hn_den = p.evse_power * p.charging_eff;
+  for (size_t k = 0; k < TN; ++k) {
+    tab[k].sor = t.soc_on_return[k];
+    tab[k].tl = t.time_left[k];
+    tab[k].there = t.there[k];
+    if (!p.aux) continue;
+    const double th = (double)t.there[k];
+    const double tgt_th = p.target_soc * th;
+    const double cl = tgt_th - t.soc_on_return[k];
+    const double hn = cl * p.batt_cap_nominal / hn_den;
+    double lax = ((double)t.time_left[k] / (hn + 0.001) - 1) * th;
+    lax = lax < 0 ? 0 : (lax > 5 ? 5 : lax);
+    AuxRec& a = aux[k];
+    a.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
+    a.cl = (float)(norm ? cl / p.max_soc : cl);
+    a.hn = (float)(norm ? hn / p.max_hours_needed : hn);
+    a.lax = (float)(norm ? lax / p.max_laxity : lax);
   }
 }
 
@@ -227,84 +265,73 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.E = E; d.N = N; d.T = T;
   d.obs_dim = obs_dim_of(p);
   d.episode_steps = p->episode_steps;
-  d.hist_cap = p->episode_steps + 2;
+  d.stack_cap = p->episode_steps + 3;
   d.tail_a_len = 2 * (L + 1) + (p->include_building ? B + 1 : 0) + (p->include_pv ? B + 1 : 0);
   d.tail_b_len = p->aux ? (1 + (p->include_building ? 3 : 0) + 6) : 0;
   d.tail_stride = ((d.tail_a_len + d.tail_b_len + 3) / 4) * 4;
   d.aux = p->aux; d.normalize = p->normalize; d.is_caretaker = p->is_caretaker; d.deg_mode = p->deg_mode;
-  d.auto_reset = p->auto_reset; d.picker_mode = p->picker_mode; d.start_lo = p->start_lo; d.start_hi = p->start_hi;
-  d.env_id_offset = p->env_id_offset; d.sched_n = 0; d.seed = p->seed;
+  d.auto_reset = p->auto_reset;
   d.dt = p->dt; d.evse_power = p->evse_power;
   d.p_avail = p->obc_max_power < p->evse_power ? p->obc_max_power : p->evse_power;  // min([obc, evse]) ev_charger.py:95
-  d.batt_cap_nominal = p->batt_cap_nominal; d.init_cap = p->init_battery_cap; d.grid_connection = p->grid_connection;
+  d.init_cap = p->init_battery_cap; d.grid_connection = p->grid_connection;
   d.eta_c = p->charging_eff; d.eta_d = p->discharging_eff; d.variable_multiplier = p->variable_multiplier;
   d.one_minus_fee = 1 - p->feed_in_deduction;
   d.penalty_invalid = p->penalty_invalid_action; d.penalty_oc = p->penalty_overcharging; d.clip_oc = p->clip_overcharging;
   d.penalty_overload = p->penalty_overloading; d.fully_charged_reward = p->fully_charged_reward;
-  d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps; d.def_soc = p->def_soc;
-  d.min_laxity = p->min_laxity; d.init_soh = p->init_soh; d.temperature = p->temperature;
-  d.hn_denominator = p->evse_power * p->charging_eff;
-  d.max_time_left = p->max_time_left; d.max_soc = p->max_soc; d.max_hours_needed = p->max_hours_needed;
-  d.max_laxity = p->max_laxity;
+  d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps;
+  d.max_time_left = p->max_time_left;
+
+  FleetCold& cd = b->cold_host;
+  cd.min_laxity = p->min_laxity; cd.def_soc = p->def_soc; cd.init_soh = p->init_soh; cd.temperature = p->temperature;
+  cd.dt = p->dt; cd.batt_cap_nominal = p->batt_cap_nominal; cd.hn_denominator = p->evse_power * p->charging_eff;
+  cd.max_soc = p->max_soc; cd.max_hours_needed = p->max_hours_needed; cd.max_laxity = p->max_laxity;
+  cd.seed = p->seed; cd.picker_mode = p->picker_mode; cd.start_lo = p->start_lo; cd.start_hi = p->start_hi;
+  cd.env_id_offset = p->env_id_offset; cd.sched_n = 0; cd.normalize = p->normalize; cd.sched = nullptr;
 
   // ---- tables ---------------------------------------------------------------------------------------
   int rc;
-  const size_t TN = (size_t)T * N;
-  if ((rc = dev_upload(b, &d.tab_there, t->there, TN))) return rc;
-  if ((rc = dev_upload(b, &d.tab_tl, t->time_left, TN))) return rc;
-  if ((rc = dev_upload(b, &d.tab_sor, t->soc_on_return, TN))) return rc;
-  std::vector<PhysRow> phys;
-  std::vector<uint8_t> flags;
-  build_phys_rows(*p, *t, phys, flags);
-  std::vector<float> tail;
-  build_tail_rows(*p, *t, d.tail_a_len, d.tail_b_len, d.tail_stride, tail);
-  if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
-  if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
-  if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
-  HIP_TRY(b, hipStreamSynchronize(b->stream));  // host vectors go out of scope below
+  {
+    std::vector<PhysRow> phys;
+    std::vector<uint8_t> flags;
+    build_phys_rows(*p, *t, phys, flags);
+    std::vector<float> tail;
+    build_tail_rows(*p, *t, d.tail_a_len, d.tail_b_len, d.tail_stride, tail);
+    std::vector<TabRec> tab;
+    std::vector<AuxRec> aux;
+    build_ev_rows(*p, *t, tab, aux);
+    if ((rc = dev_upload(b, &d.tab, tab.data(), tab.size()))) return rc;
+    if (p->aux && (rc = dev_upload(b, &d.tab_aux, aux.data(), aux.size()))) return rc;
+    if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
+    if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
+    if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
+    HIP_TRY(b, hipStreamSynchronize(b->stream));  // host vectors go out of scope here
+  }
+  if ((rc = dev_alloc(b, &b->cold_dev, 1))) return rc;
+  HIP_TRY(b, hipMemcpyAsync(b->cold_dev, &cd, sizeof(FleetCold), hipMemcpyHostToDevice, b->stream));
+  d.cold = b->cold_dev;
 
   // ---- state ----------------------------------------------------------------------------------------
   const size_t EN = (size_t)E * N;
-  if ((rc = dev_alloc(b, &d.soc, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.hl, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.soc_deg, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.soh, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.tgt090, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.rf_len, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.fd_cyc, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.fd_cal, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.sei_l, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.sei_soh, EN))) return rc;
-  if (p->deg_mode != FLEET_DEG_NONE) {
-    if ((rc = dev_alloc(b, &d.hist, EN * (size_t)d.hist_cap, false))) return rc;
-  }
+  if ((rc = dev_alloc(b, &d.hot, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.env, E))) return rc;
+  if ((rc = dev_alloc(b, &d.cold_f, EN * CP_COUNT))) return rc;
+  if ((rc = dev_alloc(b, &d.cold_i, EN * CI_COUNT))) return rc;
+  if ((rc = dev_alloc(b, &d.env_f, (size_t)E * EF_COUNT))) return rc;
+  if ((rc = dev_alloc(b, &d.env_i, (size_t)E * EI_COUNT))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
-    if ((rc = dev_alloc(b, &d.rf_stack, EN * (size_t)(d.hist_cap + 1), false))) return rc;
+    if ((rc = dev_alloc(b, &d.rf_stack, EN * (size_t)d.stack_cap, false))) return rc;
   }
-  if ((rc = dev_alloc(b, &d.t_idx, E))) return rc;
-  if ((rc = dev_alloc(b, &d.t_end, E))) return rc;
-  if ((rc = dev_alloc(b, &d.start_idx, E))) return rc;
-  if ((rc = dev_alloc(b, &d.hist_len, E))) return rc;
-  if ((rc = dev_alloc(b, &d.episodes, E))) return rc;
-  if ((rc = dev_alloc(b, &d.ep_len, E))) return rc;
-  if ((rc = dev_alloc(b, &d.last_ep_len, E))) return rc;
-  if ((rc = dev_alloc(b, &d.ep_return, E))) return rc;
-  if ((rc = dev_alloc(b, &d.last_ep_return, E))) return rc;
-  if ((rc = dev_alloc(b, &d.cashflow, E))) return rc;
-  if ((rc = dev_alloc(b, &d.penalty_record, E))) return rc;
-  if ((rc = dev_alloc(b, &d.err, E))) return rc;
-  if ((rc = dev_alloc(b, &d.done_flag, E))) return rc;
   {
-    // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66) and the
-    // initial SoH / target flags (fleet_environment.py:263)
-    std::vector<double> v(EN, p->init_soh), l(EN, 1.0 - p->init_soh);
+    // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66), the initial
+    // SoH and the (cleared) sticky target flags (fleet_environment.py:263)
+    std::vector<HotRec> hot(EN);
+    for (auto& h : hot) { h.soc = 0; h.soc_deg = 0; h.soh = p->init_soh; h.hl = 0; h.bits = 0; }
+    std::vector<double> soh(EN, p->init_soh), l(EN, 1.0 - p->init_soh);
     std::vector<int32_t> one(EN, 1);
-    std::vector<uint8_t> t9(EN, 0);
-    HIP_TRY(b, hipMemcpyAsync(d.soh, v.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.sei_soh, v.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.sei_l, l.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.rf_len, one.data(), EN * 4, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.tgt090, t9.data(), EN, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.hot, hot.data(), EN * sizeof(HotRec), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.cold_f + (size_t)CP_SEI_SOH * EN, soh.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.cold_f + (size_t)CP_SEI_L * EN, l.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.cold_i + (size_t)CI_RF_LEN * EN, one.data(), EN * 4, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
   // ---- staging for host entry points -------------------------------------------------------------------------------
@@ -316,6 +343,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &b->st_done, E))) return rc;
   if ((rc = dev_alloc(b, &b->st_mask, E))) return rc;
   if ((rc = dev_alloc(b, &b->st_dist, EN))) return rc;
+  if ((rc = dev_alloc(b, (char**)&b->st_field, EN * 8))) return rc;
   HIP_TRY(b, hipStreamSynchronize(b->stream));
   return FLEET_OK;
 }
@@ -395,13 +423,12 @@ int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episod
   if (!h || n_episodes < 0 || (n_episodes > 0 && !starts)) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  drop_graph(h);
   if (h->dev_sched) {
     (void)hipFree(h->dev_sched);
     h->dev_sched = nullptr;
   }
-  h->d.sched = nullptr;
-  h->d.sched_n = 0;
+  h->cold_host.sched = nullptr;
+  h->cold_host.sched_n = 0;
   if (n_episodes > 0) {
     const size_t n = (size_t)n_episodes * h->d.E;
     for (size_t i = 0; i < n; ++i)
@@ -411,9 +438,11 @@ int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episod
       }
     HIP_TRY(h, hipMalloc((void**)&h->dev_sched, n * sizeof(int32_t)));
     HIP_TRY(h, hipMemcpy(h->dev_sched, starts, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    h->d.sched = h->dev_sched;
-    h->d.sched_n = n_episodes;
+    h->cold_host.sched = h->dev_sched;
+    h->cold_host.sched_n = n_episodes;
   }
+  // the cold block lives in device memory, so captured graphs stay valid
+  HIP_TRY(h, hipMemcpy(h->cold_dev, &h->cold_host, sizeof(FleetCold), hipMemcpyHostToDevice));
   return FLEET_OK;
 }
 
@@ -496,44 +525,23 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
 int fleet_get(fleet_handle h, int field, void* out) {
   if (!h || !out) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
-  const FleetDev& d = h->d;
-  const size_t E = d.E, EN = (size_t)d.E * d.N;
-  const void* src = nullptr;
+  const size_t E = h->d.E, EN = (size_t)h->d.E * h->d.N;
   size_t bytes = 0;
   switch (field) {
-    case FLEET_F_SOC: src = d.soc; bytes = EN * 8; break;
-    case FLEET_F_HOURS_LEFT: src = d.hl; bytes = EN * 4; break;
-    case FLEET_F_SOH: src = d.soh; bytes = EN * 8; break;
-    case FLEET_F_SOC_DEG: src = d.soc_deg; bytes = EN * 8; break;
-    case FLEET_F_TIME_IDX: src = d.t_idx; bytes = E * 4; break;
-    case FLEET_F_START_IDX: src = d.start_idx; bytes = E * 4; break;
-    case FLEET_F_CASHFLOW: src = d.cashflow; bytes = E * 8; break;
-    case FLEET_F_EP_RETURN: src = d.ep_return; bytes = E * 8; break;
-    case FLEET_F_EP_LEN: src = d.ep_len; bytes = E * 4; break;
-    case FLEET_F_LAST_EP_RETURN: src = d.last_ep_return; bytes = E * 8; break;
-    case FLEET_F_LAST_EP_LEN: src = d.last_ep_len; bytes = E * 4; break;
-    case FLEET_F_RF_LEN: src = d.rf_len; bytes = EN * 4; break;
-    case FLEET_F_FD_CYC: src = d.fd_cyc; bytes = EN * 8; break;
-    case FLEET_F_FD_CAL: src = d.fd_cal; bytes = EN * 8; break;
-    case FLEET_F_SEI_L: src = d.sei_l; bytes = EN * 8; break;
-    case FLEET_F_ERROR_BITS: src = d.err; bytes = E * 4; break;
-    case FLEET_F_DONE: src = d.done_flag; bytes = E; break;
-    case FLEET_F_EPISODES: src = d.episodes; bytes = E * 4; break;
-    case FLEET_F_PENALTY_RECORD: src = d.penalty_record; bytes = E * 8; break;
-    case FLEET_F_TARGET_SOC: {
-      std::vector<uint8_t> f(EN);
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
-      HIP_TRY(h, hipMemcpy(f.data(), d.tgt090, EN, hipMemcpyDeviceToHost));
-      double* o = static_cast<double*>(out);
-      for (size_t i = 0; i < EN; ++i) o[i] = f[i] ? 0.9 : d.target_soc;
-      return FLEET_OK;
-    }
+    case FLEET_F_SOC: case FLEET_F_SOH: case FLEET_F_SOC_DEG: case FLEET_F_TARGET_SOC: case FLEET_F_FD_CYC:
+    case FLEET_F_FD_CAL: case FLEET_F_SEI_L: bytes = EN * 8; break;
+    case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: bytes = EN * 4; break;
+    case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD: bytes = E * 8; break;
+    case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
+    case FLEET_F_EPISODES: bytes = E * 4; break;
+    case FLEET_F_DONE: bytes = E; break;
     default:
       h->error = "fleet_get: unknown field";
       return FLEET_ERR_INVALID;
   }
+  HIP_TRY(h, fleet_launch_gather_field(h->d, field, h->st_field, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out, h->st_field, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
   return FLEET_OK;
 }
 
@@ -619,6 +627,38 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
     HIP_TRY(h, fleet_launch_step(h->d, base + (size_t)(i % tape_len) * row, act_dtype, 1, obs, reward, done, nullptr, nullptr,
                                  h->stream));
   return FLEET_OK;
+}
+
+int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
+                         double* reward, uint8_t* done, float* per_launch_ms) {
+  if (!h || steps < 1 || !tape || tape_len < 1 || !obs || !reward || !done || !per_launch_ms ||
+      (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
+    if (h) h->error = "fleet_time_steps_dev: bad argument";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
+  const char* base = static_cast<const char*>(tape);
+  std::vector<hipEvent_t> ev(2 * (size_t)steps, nullptr);
+  int rc = FLEET_OK;
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) rc = FLEET_ERR_HIP;
+  if (rc == FLEET_OK) {
+    for (int i = 0; i < steps && rc == FLEET_OK; ++i) {
+      if (hipEventRecord(ev[2 * i], h->stream) != hipSuccess) rc = FLEET_ERR_HIP;
+      if (fleet_launch_step(h->d, base + (size_t)(i % tape_len) * row, act_dtype, 1, obs, reward, done, nullptr, nullptr,
+                            h->stream) != hipSuccess)
+        rc = FLEET_ERR_HIP;
+      if (hipEventRecord(ev[2 * i + 1], h->stream) != hipSuccess) rc = FLEET_ERR_HIP;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FLEET_ERR_HIP;
+    for (int i = 0; i < steps && rc == FLEET_OK; ++i)
+      if (hipEventElapsedTime(&per_launch_ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = FLEET_ERR_HIP;
+  }
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (rc != FLEET_OK) h->error = "fleet_time_steps_dev: a HIP call failed";
+  return rc;
 }
 
 }  // extern "C"

@@ -1,82 +1,136 @@
 // fleet_device.h -- device-side view of one env batch (kernel argument block) shared by the kernels
 // (fleet_kernels.hip) and the host side of the C ABI (fleet_capi.hip).  gfx950 only.
+//
+// Layout rules (DESIGN.md "Data layout in HBM"):
+//   * everything a lane touches every step sits in ONE 32-byte record per (env, EV)  -> two 16-byte loads/stores
+//     per lane, consecutive lanes = consecutive records (a wavefront of a 50-EV env moves one 1600-byte run);
+//   * everything a group needs per env and step sits in ONE 16-byte record (broadcast load);
+//   * table values of (time row, EV) sit in 16-byte records, the env-level observation blocks and the physics
+//     scalars of a time row in contiguous rows;
+//   * rarely touched state (degradation bookkeeping) is kept in separate SoA planes so it costs nothing on the
+//     hot path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/fleet_hip.h"
 
-// Physics row: everything the charge/overload arithmetic needs at time row t, 64 B, one row per t.
-// Values are pre-combined on the host ONLY where the reference applies the very same float64 operations
-// to per-time scalars (so the result is bit-identical): see fleet_capi.hip build_phys_rows().
+// ---- read-only tables ---------------------------------------------------------------------------------------
+// Physics row of time row t (64 B).  Values are pre-combined on the host ONLY where the reference applies the
+// very same float64 operations to per-time scalars, so they are bit-identical (fleet_capi.hip build_phys_rows()).
 struct PhysRow {
-  double spot_plus_offset;  // DELU[t]/1000.0 + fixed_markup/1000            (ev_charger.py:145,149)
-  double tariff;            // tariff[t]                                     (:194)
-  double k_charge;          // -1*price_multiplier*prc[t]/1000               (:154-155)
-  double k_discharge;       // -1*price_multiplier*trc[t]/1000               (:204-205)
-  double load;              // building load [kW] or 0                       (fleet_environment.py:480-483)
-  double pv;                // pv [kW] or 0                                  (:485-488)
-  double pv_energy;         // pv[t]*dt [kWh] or 0                           (ev_charger.py:134)
+  double spot_plus_offset;  // DELU[t]/1000.0 + fixed_markup/1000                 (ev_charger.py:145,149)
+  double tariff;            // tariff[t]                                          (:194)
+  double k_charge;          // -1*price_multiplier*prc[t]/1000                    (:154-155)
+  double k_discharge;       // -1*price_multiplier*trc[t]/1000                    (:204-205)
+  double load;              // building load [kW] or 0                            (fleet_environment.py:480-483)
+  double pv;                // pv [kW] or 0                                       (:485-488)
+  double pv_share;          // pv[t]*dt / max(sum(There[t]),1)                    (ev_charger.py:134-142)
   double reserved;
+};
+
+// Table record of (time row t, EV c), 16 B.
+struct TabRec {
+  double sor;      // db["SOC_on_return"]
+  float tl;        // db["time_left"] (multiple of dt, exact in f32)
+  uint32_t there;  // db["There"]
+};
+
+// Pre-assembled auxiliary observation slots of (t, c) for the un-degraded target SOC, 16 B
+// (observer_bl_pv.py:85-91 + oracle_normalization.py:127-131), already normalised when normalize_in_env.
+struct AuxRec {
+  float tgt_th;  // target_soc * there
+  float cl;      // charging_left
+  float hn;      // hours_needed
+  float lax;     // laxity
 };
 
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
+
+// ---- state ---------------------------------------------------------------------------------------------------
+// Hot record of (env e, EV c), 32 B.
+struct HotRec {
+  double soc;      // episode.soc
+  double soc_deg;  // episode.soc_deg == last logged SOC sample (LogDataDeg.soc_log[-1])
+  double soh;      // episode.soh  (battery_cap = soh * init_battery_cap is recomputed on use)
+  float hl;        // episode.hours_left (multiple of dt, exact in f32)
+  uint32_t bits;   // [12:0] rainflow stack tail, [25:13] stack head, [27:26] sign of the last SOC slope
+                   // (0 none, 1 up, 2 down), [31] sticky "target_soc = 0.9" flag (quirk Q7)
+};
+#define HOT_TAIL(b) ((int)((b) & 0x1FFFu))
+#define HOT_HEAD(b) ((int)(((b) >> 13) & 0x1FFFu))
+#define HOT_SGN(b) ((int)(((b) >> 26) & 3u))
+#define HOT_T090(b) (((b) >> 31) != 0u)
+#define HOT_PACK(tail, head, sgn, t090) \
+  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((t090) ? 0x80000000u : 0u))
+
+// Env record, 16 B.
+struct EnvRec {
+  int32_t t;         // current table row (episode.time)
+  int32_t t_end;     // finish row (episode.finish_time)
+  int32_t nsamp;     // len(LogDataDeg.soc_log)
+  int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
+};
+
+// planes of the per-(env,EV) float64 cold state, each [E*N]
+enum ColdPlane {
+  CP_S1 = 0,      // rainflow stack[tail-2] cache
+  CP_S2,          // rainflow stack[tail-1] cache
+  CP_MEAN_SUM,    // sum of cycle means over the closed cycles of this episode
+  CP_CSUM,        // stress sum of the closed cycles with index >= rainflow_length-1
+  CP_FD_CYC,      // RainflowSeiDegradation.fd_cyc
+  CP_FD_CAL,      // .fd_cal
+  CP_SEI_L,       // .l
+  CP_SEI_SOH,     // .soh (the model's own copy, only used by its consistency check)
+  CP_COUNT
+};
+// planes of the per-(env,EV) int32 cold state
+enum ColdIPlane { CI_NC = 0 /* closed cycles this episode */, CI_RF_LEN /* rainflow_length */, CI_COUNT };
+// planes of the per-env float64 / int32 statistics
+enum EnvFPlane { EF_EP_RETURN = 0, EF_LAST_EP_RETURN, EF_CASHFLOW, EF_PENALTY_RECORD, EF_COUNT };
+enum EnvIPlane { EI_START = 0, EI_EP_LEN, EI_LAST_EP_LEN, EI_ERR, EI_DONE, EI_COUNT };
+
+// Scalars only the rare paths need (reset, daily degradation, slow observation path).  Lives in device memory and
+// is read through a pointer so that the hot path's scalar-register budget is not spent on it.
+struct FleetCold {
+  double min_laxity, def_soc, init_soh, temperature, dt;
+  double batt_cap_nominal, hn_denominator, max_soc, max_hours_needed, max_laxity;
+  unsigned long long seed;
+  int picker_mode, start_lo, start_hi, env_id_offset;
+  int sched_n;
+  int normalize;
+  const int32_t* sched;  // [sched_n, E]
+};
 
 struct FleetDev {
   // ---- sizes / flags --------------------------------------------------------------------------------
   int E, N, T;
   int obs_dim;
   int episode_steps;
-  int hist_cap;     // episode_steps + 2 rows
+  int stack_cap;    // rows of the rainflow stack workspace (episode_steps + 3)
   int tail_a_len;   // price|tariff|load|pv look-ahead block  (obs offset 2N)
   int tail_b_len;   // evse|grid|avail|pavg|6 time features   (obs offset 2N + tail_a_len + 5N), 0 if !aux
   int tail_stride;  // floats per tail row (tail_a then tail_b, padded to a multiple of 4)
   int aux, normalize, is_caretaker, deg_mode, auto_reset;
-  int picker_mode, start_lo, start_hi, env_id_offset;
-  int sched_n;
-  unsigned long long seed;
-  // ---- scalars (FleetParams) ------------------------------------------------------------------------
-  double dt, evse_power, p_avail, batt_cap_nominal, init_cap, grid_connection;
-  double eta_c, eta_d, variable_multiplier, one_minus_fee, penalty_invalid, penalty_oc, clip_oc, penalty_overload,
-      fully_charged_reward, target_soc, target_soc_lunch, eps, def_soc, min_laxity, init_soh, temperature;
-  double hn_denominator;  // evse_power * charging_eff  (observer_*.py:88)
-  double max_time_left, max_soc, max_hours_needed, max_laxity;
+  // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
+  double dt, p_avail, init_cap, eta_c, eta_d, variable_multiplier, one_minus_fee, penalty_invalid, penalty_oc, clip_oc,
+      target_soc, target_soc_lunch, eps, fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left;
   // ---- read-only tables ---------------------------------------------------------------------------------
-  const uint8_t* tab_there;  // [T,N]
-  const float* tab_tl;       // [T,N]
-  const double* tab_sor;     // [T,N]
-  const PhysRow* tab_phys;   // [T]
-  const uint8_t* tab_flags;  // [T]
-  const float* tab_tail;     // [T,tail_stride]
-  const int32_t* sched;           // [sched_n,E] injected start rows or nullptr
-  // ---- per-(env,EV) state -----------------------------------------------------------------------------
-  double* soc;       // [E,N]
-  float* hl;         // [E,N] hours_left (multiples of dt: exact in f32)
-  double* soc_deg;   // [E,N]
-  double* soh;       // [E,N]
-  uint8_t* tgt090;   // [E,N] sticky "target_soc = 0.9" flag (quirk Q7)
-  int32_t* rf_len;   // [E,N] RainflowSeiDegradation.rainflow_length
-  double* fd_cyc;    // [E,N]
-  double* fd_cal;    // [E,N]
-  double* sei_l;     // [E,N]
-  double* sei_soh;   // [E,N]
-  double* hist;      // [hist_cap, E*N]  LogDataDeg.soc_log, time-major so lanes stay coalesced
-  double* rf_stack;  // [hist_cap+1, E*N] reversal stack workspace of the rainflow replay
-  // ---- per-env state ----------------------------------------------------------------------------------
-  int32_t* t_idx;
-  int32_t* t_end;
-  int32_t* start_idx;
-  int32_t* hist_len;
-  int32_t* episodes;
-  int32_t* ep_len;
-  int32_t* last_ep_len;
-  double* ep_return;
-  double* last_ep_return;
-  double* cashflow;
-  double* penalty_record;
-  uint32_t* err;
-  uint8_t* done_flag;
+  const TabRec* tab;          // [T,N]
+  const AuxRec* tab_aux;      // [T,N] or nullptr when !aux
+  const PhysRow* tab_phys;    // [T]
+  const uint8_t* tab_flags;   // [T]
+  const float* tab_tail;      // [T,tail_stride]
+  const FleetCold* cold;
+  // ---- state ------------------------------------------------------------------------------------------
+  HotRec* hot;        // [E,N]
+  EnvRec* env;        // [E]
+  double* cold_f;     // [CP_COUNT][E*N]
+  int32_t* cold_i;    // [CI_COUNT][E*N]
+  double* env_f;      // [EF_COUNT][E]
+  int32_t* env_i;     // [EI_COUNT][E]
+  double* rf_stack;   // [stack_cap][E*N] reversal stack of the streaming rainflow (time-major: lanes stay coalesced)
 };
 
 // launchers implemented in fleet_kernels.hip
@@ -84,3 +138,5 @@ hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs
 hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                              uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s);
 hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t s);
+// unpack state planes for fleet_get: field ids of include/fleet_hip.h -> contiguous device buffer `out`
+hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s);

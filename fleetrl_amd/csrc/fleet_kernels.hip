@@ -1,6 +1,6 @@
 // fleet_kernels.hip -- the FleetEnv step / reset hot path as hand-written HIP for gfx950 (MI355X, CDNA4).
 //
-// What runs here (reference: /root/reference/fleetrl, all float64 in the reference's operation order):
+// What runs here (reference: /root/reference/fleetrl, float64 in the reference's operation order):
 //   EvCharger.charge            utils/ev_charging/ev_charger.py:39-231
 //   LoadCalculation.check_violation + ScoreConfig.overloading_penalty
 //                               utils/load_calculation/load_calculation.py:83-94, fleet_env/config/score_config.py:33-41
@@ -9,17 +9,23 @@
 //   Observer*.get_obs + Unit/OracleNormalization.normalize_obs
 //                               utils/observation/observer_*.py, utils/normalization/*.py
 //   LogDataDeg.log_soc, RainflowSeiDegradation / EmpiricalDegradation.calculate_degradation
-//                               utils/battery_degradation/*.py
+//                               utils/battery_degradation/*.py  (+ third-party rainflow.extract_cycles)
 //   FleetEnv.reset (incl. the vec-env auto-reset)  fleet_environment.py:330-434
 //
 // Mapping.  One *group* of G lanes owns one env (G = smallest power of two >= min(N,64)); a 64-lane wavefront
 // holds 64/G envs and a 256-thread workgroup 256/G.  Lane g of a group owns EVs g, g+G, ...  Per-env sums
 // (cost, revenue, reward, sum(action*there)) are reduced inside the wavefront with DPP row shifts / row
-// broadcasts -- no LDS round trip, no atomics; "connected cars" is a popcount of a wave ballot.
-// Every lane of a group tracks the per-env scalars (time row, episode end, history length) redundantly in
-// registers, so nothing written by one lane is ever re-read by another inside a launch.
-// Tables are read with the EV index fastest ([T,N] rows) and state with [E,N] rows, so a wavefront's
-// accesses are contiguous runs of N elements.  No MFMA: there is no contraction on this path.
+// broadcasts -- no LDS round trip, no atomics.  Every lane of a group tracks the per-env scalars (time row,
+// episode end, sample count) redundantly in registers, so nothing written by one lane is re-read by another
+// inside a launch.  No MFMA: there is no contraction on this path.
+//
+// Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
+// simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (reversal
+// stack in HBM, top two entries cached, slope sign, closed-cycle count, sum of cycle means, stress sum of the
+// closed cycles that fall into the reference's slice) and feeds it ONE sample per step.  On the daily 14:45 row
+// the forced last point and the residual half cycles are evaluated on a *virtual* copy of the stack (registers
+// only), which reproduces the reference's full recount, including its cross-episode bookkeeping
+// (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
 #include "fleet_device.h"
 
 namespace {
@@ -52,14 +58,6 @@ __device__ __forceinline__ double group_sum_to_last(double v) {
   return v;
 }
 
-template <int G>
-__device__ __forceinline__ int group_count(bool pred, int lane) {
-  unsigned long long m = __ballot(pred);
-  if (G == 64) return __popcll(m);
-  const int base = lane & ~(G - 1);
-  return __popcll((m >> base) & ((1ull << G) - 1ull));
-}
-
 // Philox4x32-10 start-row sampler; same specification as the oracle's (counter = (global env, episode, 0, 0)).
 __device__ __forceinline__ uint32_t philox_start(unsigned long long seed, uint32_t env, uint32_t episode) {
   uint32_t c0 = env, c1 = episode, c2 = 0, c3 = 0;
@@ -76,12 +74,12 @@ __device__ __forceinline__ uint32_t philox_start(unsigned long long seed, uint32
   return c0;
 }
 
-__device__ __forceinline__ int choose_start(const FleetDev& d, int e, int episode) {
-  if (d.sched_n > 0) return d.sched[(size_t)(episode % d.sched_n) * d.E + e];
-  if (d.picker_mode == FLEET_PICK_STATIC) return d.start_lo;
-  const uint32_t range = (uint32_t)(d.start_hi - d.start_lo + 1);
-  const uint32_t x = philox_start(d.seed, (uint32_t)(d.env_id_offset + e), (uint32_t)episode);
-  return d.start_lo + (int)__umulhi(x, range);
+__device__ __forceinline__ int choose_start(const FleetCold* cd, int E, int e, int episode) {
+  if (cd->sched_n > 0) return cd->sched[(size_t)(episode % cd->sched_n) * E + e];
+  if (cd->picker_mode == FLEET_PICK_STATIC) return cd->start_lo;
+  const uint32_t range = (uint32_t)(cd->start_hi - cd->start_lo + 1);
+  const uint32_t x = philox_start(cd->seed, (uint32_t)(cd->env_id_offset + e), (uint32_t)episode);
+  return cd->start_lo + (int)__umulhi(x, range);
 }
 
 // ScoreConfig.soc_violation_penalty (score_config.py:26-30)
@@ -98,34 +96,42 @@ __device__ __forceinline__ double overloading_penalty(double rel, double scale) 
 // ---------------------------------------------------------------------------------------------------------
 // observation assembly (observer_*.py + normalization/*.py); layout: DESIGN.md "Observation row"
 // ---------------------------------------------------------------------------------------------------------
-// per-EV slots of EV c at table row t: soc, hours_left from live state; the five aux slots from the TABLE row
-// (quirk Q10: not from live state), observer_bl_pv.py:85-91.
-__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, int t, double soc,
-                                             float hl, double tgt) {
+// Per-EV slots of EV c at table row t.  soc / hours_left come from live state; the five auxiliary slots from the
+// TABLE row (quirk Q10) -- pre-assembled on the host for the configured target SOC (AuxRec), recomputed here only
+// for an EV whose target has been raised to 0.9 (quirk Q7).
+__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, size_t ti, double soc, float hl,
+                                             bool t090, const TabRec& tb) {
   const int N = d.N;
   row[c] = (float)soc;
   row[N + c] = d.normalize ? (float)((double)hl / d.max_time_left) : hl;
   if (!d.aux) return;
-  const size_t ti = (size_t)t * N + c;
-  const double th = (double)d.tab_there[ti];
-  const double tgt_th = tgt * th;                        // target_soc * there
-  const double cl = tgt_th - d.tab_sor[ti];              // charging_left
-  const double hn = cl * d.batt_cap_nominal / d.hn_denominator;  // hours_needed
-  double lax = ((double)d.tab_tl[ti] / (hn + 0.001) - 1.0) * th;
-  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);       // np.clip(laxity, 0, 5)
   float* a = row + 2 * N + d.tail_a_len;
-  if (d.normalize) {
-    a[c] = (float)th;
-    a[N + c] = (float)(tgt_th / d.max_soc);
-    a[2 * N + c] = (float)(cl / d.max_soc);
-    a[3 * N + c] = (float)(hn / d.max_hours_needed);
-    a[4 * N + c] = (float)(lax / d.max_laxity);
+  a[c] = (float)tb.there;
+  if (!t090) {
+    const AuxRec ar = d.tab_aux[ti];
+    a[N + c] = ar.tgt_th;
+    a[2 * N + c] = ar.cl;
+    a[3 * N + c] = ar.hn;
+    a[4 * N + c] = ar.lax;
   } else {
-    a[c] = (float)th;
-    a[N + c] = (float)tgt_th;
-    a[2 * N + c] = (float)cl;
-    a[3 * N + c] = (float)hn;
-    a[4 * N + c] = (float)lax;
+    const FleetCold* cd = d.cold;
+    const double th = (double)tb.there;
+    const double tgt_th = 0.9 * th;
+    const double cl = tgt_th - tb.sor;
+    const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
+    double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
+    lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
+    if (cd->normalize) {
+      a[N + c] = (float)(tgt_th / cd->max_soc);
+      a[2 * N + c] = (float)(cl / cd->max_soc);
+      a[3 * N + c] = (float)(hn / cd->max_hours_needed);
+      a[4 * N + c] = (float)(lax / cd->max_laxity);
+    } else {
+      a[N + c] = (float)tgt_th;
+      a[2 * N + c] = (float)cl;
+      a[3 * N + c] = (float)hn;
+      a[4 * N + c] = (float)lax;
+    }
   }
 }
 
@@ -140,109 +146,155 @@ __device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// battery degradation (daily, on the 14:45 row)
+// battery degradation
 // ---------------------------------------------------------------------------------------------------------
-// RainflowSeiDegradation.calculate_degradation for one EV (rainflow_sei_degradation.py:91-212), with the
-// rainflow.extract_cycles replay fused in as a single streaming pass over the episode's SOC history:
-//   * reversal stack in HBM workspace (column i of rf_stack), bounded by the history length;
-//   * cycles are consumed the moment they are emitted: sum of means (-> mean_soc_cal), count (-> len),
-//     and the stress sum over the slice [rainflow_length-1, len-1), which needs a one-cycle delay because
-//     the slice excludes the LAST emitted cycle.
-__device__ double sei_degradation(const FleetDev& d, size_t i, int n, uint32_t& err) {
+// stress of one rainflow cycle: deg_rate_cycle(dod, avg_soc, temp) (rainflow_sei_degradation.py:68-80) for
+// effective_dod = clip(range*count, 0, 1) (:170)
+__device__ __forceinline__ double cycle_stress(double rng, double mean, double count, double stress_temp) {
+  double eff = rng * count;
+  eff = eff < 0.0 ? 0.0 : (eff > 1.0 ? 1.0 : eff);
+  const double s_dod = 1.0 / (1.4E5 * pow(eff, -5.01E-1) + -1.23E5);
+  const double s_soc = exp(1.04 * (mean - 0.5));
+  return s_dod * s_soc * stress_temp;
+}
+
+__device__ __forceinline__ double stress_temperature(double temp) {
+  return exp(6.93E-2 * (temp - 25.0) * ((25.0 + 273.15) / (temp + 273.15)));
+}
+
+// A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
+// three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
+// Stack column `stk` (row stride EN); its top two entries are cached in the CP_S1/CP_S2 planes.
+__device__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& head, uint32_t& err) {
   const size_t EN = (size_t)d.E * d.N;
-  const double* h = d.hist + i;
   double* stk = d.rf_stack + i;
-  const int L = d.rf_len[i];
-  const double k_sigma = 1.04, sigma_ref = 0.5, k_temp = 6.93E-2, temp_ref = 25.0;
-  const double stress_temp = exp(k_temp * (d.temperature - temp_ref) * ((temp_ref + 273.15) / (d.temperature + 273.15)));
+  double* cf = d.cold_f + i;
+  int32_t* ci = d.cold_i + i;
+  if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
+    err |= FLEET_DEVERR_TABLE_END;
+    return;
+  }
+  double a = cf[(size_t)CP_S1 * EN], b = cf[(size_t)CP_S2 * EN];  // stack[tail-2], stack[tail-1]
+  stk[(size_t)tail * EN] = p;
+  tail += 1;
+  int size = tail - head;  // >= 2: the episode's first sample is always on the stack
+  if (size >= 3 && !(fabs(p - b) < fabs(b - a))) {
+    const int L = ci[(size_t)CI_RF_LEN * EN];
+    int nc = ci[(size_t)CI_NC * EN];
+    double mean_sum = cf[(size_t)CP_MEAN_SUM * EN], csum = cf[(size_t)CP_CSUM * EN];
+    const double st = stress_temperature(d.cold->temperature);
+    while (size >= 3) {
+      const double X = fabs(p - b), Y = fabs(b - a);
+      if (X < Y) break;
+      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, st);
+      mean_sum += 0.5 * (a + b);
+      nc += 1;
+      if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
+        head += 1;
+        size = 2;
+      } else {  // full cycle, drop its two points -> stack = [..., p]
+        tail -= 2;
+        size -= 2;
+        stk[(size_t)(tail - 1) * EN] = p;
+        b = stk[(size_t)(tail - 2) * EN];                       // size >= 2 here
+        a = (size >= 3) ? stk[(size_t)(tail - 3) * EN] : 0.0;
+      }
+    }
+    ci[(size_t)CI_NC * EN] = nc;
+    cf[(size_t)CP_MEAN_SUM * EN] = mean_sum;
+    cf[(size_t)CP_CSUM * EN] = csum;
+  }
+  cf[(size_t)CP_S1 * EN] = b;  // stack[tail-2]
+  cf[(size_t)CP_S2 * EN] = p;  // stack[tail-1]
+}
 
-  int head = 0, tail = 0, nc = 0;
-  double mean_sum = 0.0, slice_sum = 0.0, pend = 0.0, max_dod = 0.0;
+// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
+// `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
+// residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
+// is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
+__device__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, uint32_t& err) {
+  const size_t EN = (size_t)d.E * d.N;
+  const double* stk = d.rf_stack + i;
+  double* cf = d.cold_f + i;
+  int32_t* ci = d.cold_i + i;
+  const FleetCold* cd = d.cold;
+  const int L = ci[(size_t)CI_RF_LEN * EN];
+  const int nc = ci[(size_t)CI_NC * EN];
+  const double st = stress_temperature(cd->temperature);
+
+  int nv = 0;
+  double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
   bool has_pend = false;
-
-  auto emit = [&](double xa, double xb, double count) {
-    if (has_pend) slice_sum += pend;  // the previous cycle is not the last one -> inside [L-1, len-1) if flagged
+  auto emit = [&](double x1, double x2, double count) {
+    if (has_pend) vsum += pend;  // the previous cycle is not the last one
     has_pend = false;
-    const double rng = fabs(xa - xb), mean = 0.5 * (xa + xb);
-    if (nc >= L - 1) {
-      double eff = rng * count;
-      eff = eff < 0.0 ? 0.0 : (eff > 1.0 ? 1.0 : eff);
-      const double s_dod = 1.0 / (1.4E5 * pow(eff, -5.01E-1) + -1.23E5);
-      const double s_soc = exp(k_sigma * (mean - sigma_ref));
-      pend = s_dod * s_soc * stress_temp;
+    const double rng = fabs(x1 - x2), mean = 0.5 * (x1 + x2);
+    if (nc + nv >= L - 1) {
+      pend = cycle_stress(rng, mean, count, st);
       has_pend = true;
       max_dod = rng > max_dod ? rng : max_dod;
     }
-    mean_sum += mean;
-    ++nc;
+    vmean += mean;
+    nv += 1;
   };
-  auto push = [&](double x) {
-    stk[(size_t)tail * EN] = x;
-    ++tail;
-    while (tail - head >= 3) {
-      const double x1 = stk[(size_t)(tail - 3) * EN], x2 = stk[(size_t)(tail - 2) * EN], x3 = stk[(size_t)(tail - 1) * EN];
-      const double X = fabs(x3 - x2), Y = fabs(x2 - x1);
+  if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
+    int vt = tail, vh = head;
+    int size = vt - vh + 1;
+    double a = cf[(size_t)CP_S1 * EN], b = cf[(size_t)CP_S2 * EN];
+    while (size >= 3) {
+      const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
-      if (tail - head == 3) {
-        emit(x1, x2, 0.5);
-        ++head;
+      emit(a, b, (size == 3) ? 0.5 : 1.0);
+      if (size == 3) {
+        vh += 1;
+        size = 2;
       } else {
-        emit(x1, x2, 1.0);
-        stk[(size_t)(tail - 3) * EN] = x3;
-        tail -= 2;
+        vt -= 2;
+        size -= 2;
+        b = stk[(size_t)(vt - 1) * EN];
+        a = (size >= 3) ? stk[(size_t)(vt - 2) * EN] : 0.0;
       }
     }
-  };
-
-  if (n >= 2) {
-    double x_last = h[0], x = h[EN];
-    double d_last = x - x_last;
-    push(x_last);
-    double x_next = 0.0;
-    for (int k = 2; k < n; ++k) {
-      x_next = h[(size_t)k * EN];
-      if (x_next == x) continue;
-      const double d_next = x_next - x;
-      if (d_last * d_next < 0.0) push(x);
-      x = x_next;
-      d_last = d_next;
+    // remaining ranges are half cycles: stack[vh..vt) followed by the forced point
+    double prev = (vt - vh >= 2) ? stk[(size_t)vh * EN] : b;
+    for (int j = vh + 1; j < vt; ++j) {
+      const double cur = (j == vt - 1) ? b : stk[(size_t)j * EN];
+      emit(prev, cur, 0.5);
+      prev = cur;
     }
-    if (n > 2) push(x_next);
-    while (tail - head > 1) {
-      emit(stk[(size_t)head * EN], stk[(size_t)(head + 1) * EN], 0.5);
-      ++head;
-    }
+    emit(b, v, 0.5);
   }
 
   double degradation = 0.0;
-  if (nc > 0 && nc > L) {
+  const int len = nc + nv;
+  if (len > 0 && len > L) {
     if (max_dod > 5.0) err |= FLEET_DEVERR_DOD_RANGE;
-    const double battery_age = (double)(n - 1) * d.dt * 3600.0;  // max(End) is always the last sample
-    const double mean_soc_cal = mean_sum / (double)nc;
-    const double fd_cyc = d.fd_cyc[i] + slice_sum;
-    const double fd_cal = (4.14E-10 * battery_age) * exp(k_sigma * (mean_soc_cal - sigma_ref)) * stress_temp;
+    const double battery_age = (double)(n - 1) * cd->dt * 3600.0;  // max(End) is always the last sample's index
+    const double mean_soc_cal = (cf[(size_t)CP_MEAN_SUM * EN] + vmean) / (double)len;
+    const double fd_cyc = cf[(size_t)CP_FD_CYC * EN] + (cf[(size_t)CP_CSUM * EN] + vsum);
+    const double fd_cal = (4.14E-10 * battery_age) * exp(1.04 * (mean_soc_cal - 0.5)) * st;
     const double fd = fd_cyc + fd_cal;
     const double alpha = 5.75E-2, beta = 121.0;
     const double new_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
     if (new_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
-    degradation = new_l - d.sei_l[i];
-    d.fd_cyc[i] = fd_cyc;
-    d.fd_cal[i] = fd_cal;
-    d.sei_l[i] = new_l;
-    d.rf_len[i] = nc;
+    degradation = new_l - cf[(size_t)CP_SEI_L * EN];
+    cf[(size_t)CP_FD_CYC * EN] = fd_cyc;
+    cf[(size_t)CP_FD_CAL * EN] = fd_cal;
+    cf[(size_t)CP_SEI_L * EN] = new_l;
+    ci[(size_t)CI_RF_LEN * EN] = len;
+    cf[(size_t)CP_CSUM * EN] = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
   }
-  const double s = d.sei_soh[i] - degradation;
-  d.sei_soh[i] = s;
-  if (fabs(s - (1.0 - d.sei_l[i])) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
+  const double s = cf[(size_t)CP_SEI_SOH * EN] - degradation;
+  cf[(size_t)CP_SEI_SOH * EN] = s;
+  if (fabs(s - (1.0 - cf[(size_t)CP_SEI_L * EN])) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
 }
 
-// EmpiricalDegradation.calculate_degradation for one EV (empirical_degradation.py:29-99; quirks Q1, Q5).
-__device__ __forceinline__ double linear_degradation(const FleetDev& d, size_t i, int n) {
-  const size_t EN = (size_t)d.E * d.N;
-  const double old_soc = d.hist[(size_t)(n - 2) * EN + i], new_soc = d.hist[(size_t)(n - 1) * EN + i];
+// EmpiricalDegradation.calculate_degradation for one EV (empirical_degradation.py:29-99; quirks Q1, Q5):
+// the last two log entries are the SOC sample before and after this step.
+__device__ __forceinline__ double linear_degradation(const FleetDev& d, double old_soc, double new_soc) {
   const double avg = (old_soc + new_soc) / 2.0;
-  // nearest of {0, 40, 90} to a SOC in [0,1] scale -- replicated literally (argmin, first wins ties)
+  // nearest of {0, 40, 90} to a SOC on a [0,1] scale -- replicated literally (argmin, first wins ties)
   int best = 0;
   double bd = fabs(0.0 - avg);
   if (fabs(40.0 - avg) < bd) { best = 1; bd = fabs(40.0 - avg); }
@@ -256,47 +308,54 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, size_t i
 // ---------------------------------------------------------------------------------------------------------
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
-struct EnvRegs {  // per-env scalars, tracked redundantly by every lane of the group
-  int t, t_end, hist_len, episodes;
-};
-
 template <int G>
-__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRegs& r, float* __restrict__ obs_row) {
+__device__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& r, float* __restrict__ obs_row) {
   const int N = d.N;
   const size_t EN = (size_t)d.E * N;
-  const int start = choose_start(d, e, r.episodes);
+  const FleetCold* cd = d.cold;
+  const int start = choose_start(cd, d.E, e, r.episodes);
   r.t = start;
   r.t_end = start + d.episode_steps;
-  r.hist_len = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
+  r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
-    const double soh = 1.0 * d.init_soh;
+    const TabRec tb = d.tab[ti];
+    const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
+    const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
-    double soc = d.tab_sor[ti];
-    const float hl = d.tab_tl[ti];
-    const double tgt = d.tgt090[i] ? 0.9 : d.target_soc;  // target_soc survives reset (quirk Q7)
-    const double time_needed = (tgt - soc) * cap / d.p_avail;               // :384
-    if ((hl > 0.0f) && (d.min_laxity * time_needed > (double)hl))           // :388
-      soc = tgt - (time_needed * d.p_avail / cap) / d.min_laxity;           // :389-390
-    const double soc_deg = (soc == 0.0) ? d.def_soc : soc;                  // :395-399
-    d.soc[i] = soc;
-    d.hl[i] = hl;
-    d.soc_deg[i] = soc_deg;
-    d.soh[i] = soh;
-    if (d.deg_mode != FLEET_DEG_NONE) d.hist[i] = soc_deg;                  // :417-418 (row 0)
-    if (obs_row) write_obs_ev(d, obs_row, c, start, soc, hl, tgt);
+    double soc = tb.sor;
+    const float hl = tb.tl;
+    const double tgt = t090 ? 0.9 : d.target_soc;
+    const double time_needed = (tgt - soc) * cap / d.p_avail;              // :384
+    if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
+      soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
+    const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
+    HotRec h;
+    h.soc = soc;
+    h.soc_deg = soc_deg;
+    h.soh = soh;
+    h.hl = hl;
+    h.bits = HOT_PACK(1, 0, 0, t090);  // rainflow: the first sample is the first reversal point
+    d.hot[i] = h;
+    if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
+      d.rf_stack[i] = soc_deg;
+      d.cold_f[(size_t)CP_S1 * EN + i] = 0.0;
+      d.cold_f[(size_t)CP_S2 * EN + i] = soc_deg;
+      d.cold_f[(size_t)CP_MEAN_SUM * EN + i] = 0.0;
+      d.cold_f[(size_t)CP_CSUM * EN + i] = 0.0;
+      d.cold_i[(size_t)CI_NC * EN + i] = 0;
+    }
+    if (obs_row) write_obs_ev(d, obs_row, c, ti, soc, hl, t090, tb);
   }
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
   if (leader) {
-    d.t_idx[e] = start;
-    d.t_end[e] = r.t_end;
-    d.start_idx[e] = start;
-    d.hist_len[e] = r.hist_len;
-    d.ep_return[e] = 0.0;
-    d.ep_len[e] = 0;
-    d.penalty_record[e] = 0.0;
-    d.done_flag[e] = 0;
-    if (r.t_end > d.T - 1) d.err[e] |= FLEET_DEVERR_TABLE_END;
+    d.env[e] = r;
+    d.env_i[(size_t)EI_START * d.E + e] = start;
+    d.env_f[(size_t)EF_EP_RETURN * d.E + e] = 0.0;
+    d.env_i[(size_t)EI_EP_LEN * d.E + e] = 0;
+    d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e] = 0.0;
+    d.env_i[(size_t)EI_DONE * d.E + e] = 0;
+    if (r.t_end > d.T - 1) atomicOr((unsigned int*)&d.env_i[(size_t)EI_ERR * d.E + e], FLEET_DEVERR_TABLE_END);
   }
 }
 
@@ -306,26 +365,21 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   const int e = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (e >= d.E) return;
   if (mask && !mask[e]) return;
-  EnvRegs r;
-  r.episodes = d.episodes[e];
+  EnvRec r = d.env[e];
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
-  if (d.ep_len[e] > 0 && !d.done_flag[e]) {
-    r.episodes += 1;
-    if (g == G - 1) d.episodes[e] = r.episodes;
-  }
+  if (d.env_i[(size_t)EI_EP_LEN * d.E + e] > 0 && !d.env_i[(size_t)EI_DONE * d.E + e]) r.episodes += 1;
   reset_env<G>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // the step (FleetEnv.step, fleet_environment.py:436-702), K consecutive steps per launch
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG, typename ActT>
-__global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const ActT* __restrict__ actions, int K,
-                                                            float* __restrict__ obs, double* __restrict__ reward,
-                                                            uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
-                                                            int32_t* __restrict__ done_count) {
+template <int G, int DEG>
+__global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
+                                                               float* __restrict__ obs, double* __restrict__ reward,
+                                                               uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
+                                                               int32_t* __restrict__ done_count) {
   const int N = d.N;
-  const int lane = threadIdx.x & 63;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
   const int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
@@ -333,13 +387,14 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
   const int e = env_ok ? e_raw : d.E - 1;
   const size_t EN = (size_t)d.E * N;
 
-  EnvRegs r;
-  r.t = d.t_idx[e];
-  r.t_end = d.t_end[e];
-  r.hist_len = d.hist_len[e];
-  r.episodes = d.episodes[e];
-  double ep_return = d.ep_return[e], penalty_record = d.penalty_record[e];
-  int ep_len = d.ep_len[e];
+  EnvRec r = d.env[e];
+  double ep_return = 0.0, penalty_record = 0.0;
+  int ep_len = 0;
+  if (leader) {
+    ep_return = d.env_f[(size_t)EF_EP_RETURN * d.E + e];
+    penalty_record = d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e];
+    ep_len = d.env_i[(size_t)EI_EP_LEN * d.E + e];
+  }
   uint32_t err = 0;
   double reward_sum = 0.0;
   int n_done = 0;
@@ -356,33 +411,25 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
     float* const step_row = resets ? term_row : obs_row;
     const bool write_step_obs = env_ok && (step_row != nullptr);
 
-    // ---- connected cars = sum(There[t]) (ev_charger.py:138-140) ----------------------------------------------
-    int connected = 0;
-    for (int c0 = 0; c0 < N; c0 += G) {
-      const int c = c0 + g;
-      const bool th = (c < N) && (d.tab_there[(size_t)t * N + c] != 0);
-      connected += group_count<G>(th, lane);
-    }
-    connected = connected < 1 ? 1 : connected;
-
     const PhysRow ph = d.tab_phys[t];
-    const double pv_share = ph.pv_energy / (double)connected;  // current_pv_energy / connected_cars (:142)
-    const uint8_t flags1 = d.tab_flags[t1];
+    const uint32_t flags1 = d.tab_flags[t1];
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
-    const ActT* __restrict__ act = actions + ((size_t)k * d.E + e) * N;
+    const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
+    const size_t abase = ((size_t)k * d.E + e) * N;
 
     double cost = 0.0, rev = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0;
     for (int c = g; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
-      const size_t ti = (size_t)t * N + c, ti1 = (size_t)t1 * N + c;
-      const double a = (double)act[c];
-      const int th = d.tab_there[ti];
-      double soc = d.soc[i];
-      float hl = d.hl[i];
-      const double soh = d.soh[i];
-      const double cap = soh * d.init_cap;
-      bool t090 = d.tgt090[i] != 0;
-      double tgt = t090 ? 0.9 : d.target_soc;
+      const size_t ti1 = (size_t)t1 * N + c;
+      HotRec h = d.hot[i];
+      const TabRec tb1 = d.tab[ti1];
+      const uint32_t th = d.tab[(size_t)t * N + c].there;
+      const double a = act_f64 ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
+      double soc = h.soc;
+      float hl = h.hl;
+      const double cap = h.soh * d.init_cap;
+      bool t090 = HOT_T090(h.bits);
+      const double tgt = t090 ? 0.9 : d.target_soc;
 
       // ---- EvCharger.charge (ev_charger.py:89-222) ---------------------------------------------------------
       if (a >= 0.0) {
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
           rew += pen;
         }
         double en;
-        if (th == 1) {
+        if (th == 1u) {
           const double lim = need / d.eta_c;  // :114
           en = lim < dem ? lim : dem;
         } else {
@@ -403,32 +450,32 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
           if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :120-122
         }
         soc = soc + en * d.eta_c / cap;  // :128
-        double grid_e = en - pv_share;   // :142
+        double grid_e = en - ph.pv_share;  // :142
         grid_e = grid_e > 0.0 ? grid_e : 0.0;
         cost += grid_e * ph.spot_plus_offset * d.variable_multiplier;  // :149
         rew += ph.k_charge * grid_e;                                   // :154-156
       } else {
         const double left = -1.0 * soc * cap;     // :161
         const double dem = d.p_avail * a * d.dt;  // :162
-        if ((dem * d.eta_d < left) && (th != 0)) {  // :165-167 (no clip, needs presence)
+        if ((dem * d.eta_d < left) && (th != 0u)) {  // :165-167 (no clip, needs presence)
           const double x = left - dem;
           rew += d.penalty_oc * (x * x);
         }
         double en;
-        if (th == 1) {
+        if (th == 1u) {
           en = left > dem ? left : dem;  // :174
         } else {
           en = 0.0;
           if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :180-182
         }
-        soc = soc + en / cap;                                                 // :189
-        rev += -1.0 * en * d.eta_d * ph.tariff / 1000.0 * d.one_minus_fee;    // :196-199
-        rew += ph.k_discharge * en;                                           // :204-206
+        soc = soc + en / cap;                                                // :189
+        rev += -1.0 * en * d.eta_d * ph.tariff / 1000.0 * d.one_minus_fee;   // :196-199
+        rew += ph.k_discharge * en;                                          // :204-206
       }
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
-      const float ntl = d.tab_tl[ti1];
+      const float ntl = tb1.tl;
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
         const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
@@ -442,45 +489,43 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       }
       if ((ntl != 0.0f) && (hl != 0.0f)) {  // still charging :593-594
         hl = (float)((double)hl - d.dt);
-      } else if (ntl == 0.0f) {  // no car in the next step :597-599
+      } else {  // no car in the next step :597-599, or new arrival :602-606 (the reference's `else: raise` is unreachable)
         hl = ntl;
-        soc = d.tab_sor[ti1];
-      } else {  // new arrival :602-606  (hl == 0 && ntl != 0; the reference's `else: raise` is unreachable)
-        hl = ntl;
-        soc = d.tab_sor[ti1];
+        soc = tb1.sor;
       }
-      if (soh <= 0.9) {  // :613-614 sticky target (quirk Q7)
-        t090 = true;
-        tgt = 0.9;
+      if (h.soh <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
+      const double old_deg = h.soc_deg;
+      const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
+
+      // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
+      if (write_step_obs) write_obs_ev(d, step_row, c, ti1, soc, hl, t090, tb1);
+
+      // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
+      int tail = HOT_TAIL(h.bits), head = HOT_HEAD(h.bits), sgn = HOT_SGN(h.bits);
+      double soh = h.soh;
+      if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
+        // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes
+        // the previous sample a reversal point
+        if (soc_deg != old_deg) {
+          const int s_next = (soc_deg > old_deg) ? 1 : 2;
+          if (sgn != 0 && sgn != s_next) rf_push(d, i, old_deg, tail, head, err);
+          sgn = s_next;
+        }
+        if (deg_row) soh = soh - sei_evaluate(d, i, soc_deg, r.nsamp + 1, tail, head, err);  // :666-671
       }
-      double soc_deg = d.soc_deg[i];
-      if (hl != 0.0f) soc_deg = soc;  // :621-623
+      if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
       if (env_ok) {
-        d.soc[i] = soc;
-        d.hl[i] = hl;
-        d.soc_deg[i] = soc_deg;
-        if (t090) d.tgt090[i] = 1;
-      }
-      // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ----------------------------
-      if (write_step_obs) write_obs_ev(d, step_row, c, t1, soc, hl, tgt);
-
-      // ---- SOC log + daily degradation (:655-673) ---------------------------------------------------------------
-      if (DEG != FLEET_DEG_NONE) {
-        if (r.hist_len < d.hist_cap) {
-          if (env_ok) d.hist[(size_t)r.hist_len * EN + i] = soc_deg;
-        } else {
-          err |= FLEET_DEVERR_TABLE_END;
-        }
-        if ((flags1 & FLEET_TFLAG_DEG) && env_ok) {
-          const int n = r.hist_len < d.hist_cap ? r.hist_len + 1 : d.hist_cap;
-          const double deg = (DEG == FLEET_DEG_RAINFLOW) ? sei_degradation(d, i, n, err) : linear_degradation(d, i, n);
-          d.soh[i] = soh - deg;  // :671 ; battery_cap = soh * init_cap is recomputed from soh on use (:673)
-        }
+        h.soc = soc;
+        h.soc_deg = soc_deg;
+        h.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
+        h.hl = hl;
+        h.bits = HOT_PACK(tail, head, sgn, t090);
+        d.hot[i] = h;
       }
     }
     if (write_step_obs) write_obs_tail<G>(d, step_row, t1, g);
-    if (DEG != FLEET_DEG_NONE && r.hist_len < d.hist_cap) r.hist_len += 1;
+    if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
     cost = group_sum_to_last<G>(cost);
@@ -493,8 +538,8 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       const double cashflow = -1.0 * cost + rev;  // ev_charger.py:225
       penalty_record += penrec;
       // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
-      const double head = d.grid_connection - ph.load - asum * d.evse_power + ph.pv;
-      const double over = fabs(head < 0.0 ? head : 0.0);
+      const double head_room = d.grid_connection - ph.load - asum * d.evse_power + ph.pv;
+      const double over = fabs(head_room < 0.0 ? head_room : 0.0);
       if (over > 0.0) {
         const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
         rew += pen;
@@ -504,7 +549,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       ep_len += 1;
       reward_sum += rew;
       if (env_ok) {
-        d.cashflow[e] = cashflow;
+        d.env_f[(size_t)EF_CASHFLOW * d.E + e] = cashflow;
         if (K == 1) {
           reward[e] = rew;
           done[e] = is_done ? 1 : 0;
@@ -514,18 +559,18 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
     if (is_done) {
       n_done += 1;
       if (leader && env_ok) {
-        d.last_ep_return[e] = ep_return;
-        d.last_ep_len[e] = ep_len;
-        d.done_flag[e] = 1;
+        d.env_f[(size_t)EF_LAST_EP_RETURN * d.E + e] = ep_return;
+        d.env_i[(size_t)EI_LAST_EP_LEN * d.E + e] = ep_len;
+        d.env_i[(size_t)EI_DONE * d.E + e] = 1;
       }
       r.episodes += 1;
       if (resets) {
         if (env_ok) {
           reset_env<G>(d, e, g, leader, r, obs_row);
         } else {  // surplus group: keep its registers moving without touching memory
-          r.t = choose_start(d, e, r.episodes);
+          r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = r.t + d.episode_steps;
-          r.hist_len = (DEG != FLEET_DEG_NONE) ? 1 : 0;
+          r.nsamp = (DEG != FLEET_DEG_NONE) ? 1 : 0;
         }
         ep_return = 0.0;
         ep_len = 0;
@@ -535,18 +580,16 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
   }
 
   if (leader && env_ok) {
-    d.t_idx[e] = r.t;
-    d.hist_len[e] = r.hist_len;
-    d.episodes[e] = r.episodes;
-    d.ep_return[e] = ep_return;
-    d.ep_len[e] = ep_len;
-    d.penalty_record[e] = penalty_record;
+    d.env[e] = r;
+    d.env_f[(size_t)EF_EP_RETURN * d.E + e] = ep_return;
+    d.env_i[(size_t)EI_EP_LEN * d.E + e] = ep_len;
+    d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e] = penalty_record;
     if (K != 1) {
       reward[e] = reward_sum;
       if (done_count) done_count[e] = n_done;
     }
   }
-  if (err && env_ok) atomicOr(&d.err[e], err);
+  if (err && env_ok) atomicOr((unsigned int*)&d.env_i[(size_t)EI_ERR * d.E + e], err);
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)
@@ -554,12 +597,45 @@ __global__ void fleet_dist_factor_kernel(FleetDev d, double* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)d.E * d.N) return;
   const int e = (int)(i / d.N), c = (int)(i % d.N);
-  const size_t ti = (size_t)d.t_idx[e] * d.N + c;
-  const double th = (double)d.tab_there[ti];
-  const double tgt = d.tgt090[i] ? 0.9 : d.target_soc;
-  const double cl = tgt * th - d.tab_sor[ti];
-  const double hn = cl * d.batt_cap_nominal / d.hn_denominator;
-  out[i] = hn / ((double)d.tab_tl[ti] + 0.001);
+  const TabRec tb = d.tab[(size_t)d.env[e].t * d.N + c];
+  const double th = (double)tb.there;
+  const double tgt = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc;
+  const double cl = tgt * th - tb.sor;
+  const double hn = cl * d.cold->batt_cap_nominal / d.cold->hn_denominator;
+  out[i] = hn / ((double)tb.tl + 0.001);
+}
+
+// fleet_get: unpack one field into a contiguous buffer (types as documented in include/fleet_hip.h)
+__global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t E = d.E, EN = (size_t)d.E * d.N;
+  const bool per_car = field == FLEET_F_SOC || field == FLEET_F_HOURS_LEFT || field == FLEET_F_SOH || field == FLEET_F_SOC_DEG ||
+                       field == FLEET_F_TARGET_SOC || field == FLEET_F_RF_LEN || field == FLEET_F_FD_CYC ||
+                       field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
+  if (i >= (per_car ? EN : E)) return;
+  switch (field) {
+    case FLEET_F_SOC: ((double*)out)[i] = d.hot[i].soc; break;
+    case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot[i].hl; break;
+    case FLEET_F_SOH: ((double*)out)[i] = d.hot[i].soh; break;
+    case FLEET_F_SOC_DEG: ((double*)out)[i] = d.hot[i].soc_deg; break;
+    case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc; break;
+    case FLEET_F_RF_LEN: ((int32_t*)out)[i] = d.cold_i[(size_t)CI_RF_LEN * EN + i]; break;
+    case FLEET_F_FD_CYC: ((double*)out)[i] = d.cold_f[(size_t)CP_FD_CYC * EN + i]; break;
+    case FLEET_F_FD_CAL: ((double*)out)[i] = d.cold_f[(size_t)CP_FD_CAL * EN + i]; break;
+    case FLEET_F_SEI_L: ((double*)out)[i] = d.cold_f[(size_t)CP_SEI_L * EN + i]; break;
+    case FLEET_F_TIME_IDX: ((int32_t*)out)[i] = d.env[i].t; break;
+    case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env_i[(size_t)EI_START * E + i]; break;
+    case FLEET_F_CASHFLOW: ((double*)out)[i] = d.env_f[(size_t)EF_CASHFLOW * E + i]; break;
+    case FLEET_F_EP_RETURN: ((double*)out)[i] = d.env_f[(size_t)EF_EP_RETURN * E + i]; break;
+    case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env_i[(size_t)EI_EP_LEN * E + i]; break;
+    case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env_f[(size_t)EF_LAST_EP_RETURN * E + i]; break;
+    case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env_i[(size_t)EI_LAST_EP_LEN * E + i]; break;
+    case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = (uint32_t)d.env_i[(size_t)EI_ERR * E + i]; break;
+    case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)d.env_i[(size_t)EI_DONE * E + i]; break;
+    case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].episodes; break;
+    case FLEET_F_PENALTY_RECORD: ((double*)out)[i] = d.env_f[(size_t)EF_PENALTY_RECORD * E + i]; break;
+    default: break;
+  }
 }
 
 int group_size(int N) {
@@ -573,12 +649,8 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
-  if (act_dtype == FLEET_ACT_F64)
-    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, double>), grid, block, 0, s, d, (const double*)actions, K, obs, reward,
-                       done, terminal_obs, done_count);
-  else
-    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, float>), grid, block, 0, s, d, (const float*)actions, K, obs, reward,
-                       done, terminal_obs, done_count);
+  hipLaunchKernelGGL((fleet_step_kernel<G, DEG>), grid, block, 0, s, d, actions, act_dtype == FLEET_ACT_F64 ? 1 : 0, K, obs,
+                     reward, done, terminal_obs, done_count);
   return hipGetLastError();
 }
 
@@ -628,5 +700,11 @@ hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dty
 hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t s) {
   const size_t n = (size_t)d.E * d.N;
   hipLaunchKernelGGL(fleet_dist_factor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, out);
+  return hipGetLastError();
+}
+
+hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s) {
+  const size_t n = (size_t)d.E * d.N;
+  hipLaunchKernelGGL(fleet_gather_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, field, out);
   return hipGetLastError();
 }

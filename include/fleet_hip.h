@@ -211,6 +211,11 @@ int fleet_timer_stop(fleet_handle h, float* elapsed_ms);  /* synchronises on the
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
 
+/* like fleet_run_tape_dev without a graph, but brackets EVERY launch with its own HIP event pair on the handle's
+ * stream and returns the per-launch device durations in milliseconds (HOST array [steps]); synchronous. */
+int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
+                         double* reward, uint8_t* done, float* per_launch_ms);
+
 #ifdef __cplusplus
 }
 #endif
