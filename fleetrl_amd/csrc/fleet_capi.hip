@@ -37,6 +37,7 @@ struct Batch {
   int32_t* dev_sched = nullptr;
   FleetCold cold_host{};
   FleetCold* cold_dev = nullptr;
+  FleetDev* self_dev = nullptr;
   void* st_field = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   // cached tape graph
@@ -192,8 +193,8 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
   const double spot_offset = p.fixed_markup / 1000;  // ev_charger.py:34
   for (int r = 0; r < T; ++r) {
     PhysRow& q = phys[r];
-    q.spot_plus_offset = t.delu[r] / 1000.0 + spot_offset;        // (current_spot + self.spot_offset) :145,149
-    q.tariff = t.tariff[r];
+    q.k_cost = (t.delu[r] / 1000.0 + spot_offset) * p.variable_multiplier;  // (current_spot + spot_offset) * spot_multiplier :145-149
+    q.k_rev = -1 * p.discharging_eff * t.tariff[r] / 1000 * (1 - p.feed_in_deduction);  // :196-199 without the energy factor
     q.k_charge = -1 * p.price_multiplier * t.prc[r] / 1000;       // :154-155
     q.k_discharge = -1 * p.price_multiplier * t.trc[r] / 1000;    // :204-205
     q.load = p.include_building ? t.load[r] : 0.0;
@@ -205,12 +206,13 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
     if (connected < 1) connected = 1;
     const double pv_energy = p.include_pv ? t.pv[r] * p.dt : 0.0;
     q.pv_share = pv_energy / (double)connected;
-    q.reserved = 0.0;
+    q.pad = 0;
     uint8_t f = 0;
     if (t.hour[r] == 14 && t.minute[r] == 45) f |= FLEET_TFLAG_DEG;
     if (t.hour[r] > 11 && t.hour[r] < 15) f |= FLEET_TFLAG_LUNCH;
     flags[r] = f;
   }
+  for (int r = 0; r < T; ++r) phys[r].flags_next = flags[r + 1 < T ? r + 1 : T - 1];
 }
 
 // Per-(t, EV) records: the three schedule columns packed into 16 bytes, and the five auxiliary observation
@@ -274,8 +276,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.dt = p->dt; d.evse_power = p->evse_power;
   d.p_avail = p->obc_max_power < p->evse_power ? p->obc_max_power : p->evse_power;  // min([obc, evse]) ev_charger.py:95
   d.init_cap = p->init_battery_cap; d.grid_connection = p->grid_connection;
-  d.eta_c = p->charging_eff; d.eta_d = p->discharging_eff; d.variable_multiplier = p->variable_multiplier;
-  d.one_minus_fee = 1 - p->feed_in_deduction;
+  d.eta_c = p->charging_eff; d.eta_d = p->discharging_eff;
+  // stress_temp (rainflow_sei_degradation.py:72-73) is a constant of the batch
+  d.stress_temp = std::exp(6.93E-2 * (p->temperature - 25.0) * ((25.0 + 273.15) / (p->temperature + 273.15)));
   d.penalty_invalid = p->penalty_invalid_action; d.penalty_oc = p->penalty_overcharging; d.clip_oc = p->clip_overcharging;
   d.penalty_overload = p->penalty_overloading; d.fully_charged_reward = p->fully_charged_reward;
   d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps;
@@ -320,6 +323,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &d.env_i, (size_t)E * EI_COUNT))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
     if ((rc = dev_alloc(b, &d.rf_stack, EN * (size_t)d.stack_cap, false))) return rc;
+    if ((rc = dev_alloc(b, &d.rf_top, EN))) return rc;
   }
   {
     // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66), the initial
@@ -334,6 +338,10 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     HIP_TRY(b, hipMemcpyAsync(d.cold_i + (size_t)CI_RF_LEN * EN, one.data(), EN * 4, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
+  // device-resident copy of the argument block for the out-of-line rare paths (reset, daily degradation)
+  if ((rc = dev_alloc(b, &b->self_dev, 1))) return rc;
+  d.self = b->self_dev;
+  HIP_TRY(b, hipMemcpyAsync(b->self_dev, &d, sizeof(FleetDev), hipMemcpyHostToDevice, b->stream));
   // ---- staging for host entry points -------------------------------------------------------------------------------
   const size_t OD = (size_t)E * d.obs_dim;
   if ((rc = dev_alloc(b, (char**)&b->st_actions, EN * 8))) return rc;

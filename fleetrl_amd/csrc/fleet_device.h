@@ -16,17 +16,19 @@
 #include "../../include/fleet_hip.h"
 
 // ---- read-only tables ---------------------------------------------------------------------------------------
-// Physics row of time row t (64 B).  Values are pre-combined on the host ONLY where the reference applies the
-// very same float64 operations to per-time scalars, so they are bit-identical (fleet_capi.hip build_phys_rows()).
+// Physics row of time row t (64 B): per-time scalars pre-combined on the host (fleet_capi.hip build_phys_rows()).
+// k_charge / k_discharge / pv_share use exactly the reference's float64 operations (bit-identical); k_cost / k_rev
+// re-associate two multiplications of the money terms (cashflow differs from the reference by <= 1 ulp per EV).
 struct PhysRow {
-  double spot_plus_offset;  // DELU[t]/1000.0 + fixed_markup/1000                 (ev_charger.py:145,149)
-  double tariff;            // tariff[t]                                          (:194)
-  double k_charge;          // -1*price_multiplier*prc[t]/1000                    (:154-155)
-  double k_discharge;       // -1*price_multiplier*trc[t]/1000                    (:204-205)
-  double load;              // building load [kW] or 0                            (fleet_environment.py:480-483)
-  double pv;                // pv [kW] or 0                                       (:485-488)
-  double pv_share;          // pv[t]*dt / max(sum(There[t]),1)                    (ev_charger.py:134-142)
-  double reserved;
+  double k_cost;        // (DELU[t]/1000.0 + fixed_markup/1000) * variable_multiplier : EUR per kWh drawn (ev_charger.py:145-149)
+  double k_rev;         // -1 * discharging_eff * tariff[t] / 1000 * (1 - fee)        : EUR per kWh of (negative) energy (:196-199)
+  double k_charge;      // -1*price_multiplier*prc[t]/1000                              (:154-155)
+  double k_discharge;   // -1*price_multiplier*trc[t]/1000                              (:204-205)
+  double load;          // building load [kW] or 0                                      (fleet_environment.py:480-483)
+  double pv;            // pv [kW] or 0                                                 (:485-488)
+  double pv_share;      // pv[t]*dt / max(sum(There[t]),1)                              (ev_charger.py:134-142)
+  uint32_t flags_next;  // FLEET_TFLAG_* of time row t+1 (the row the step advances to)
+  uint32_t pad;
 };
 
 // Table record of (time row t, EV c), 16 B.
@@ -56,14 +58,16 @@ struct HotRec {
   double soh;      // episode.soh  (battery_cap = soh * init_battery_cap is recomputed on use)
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
   uint32_t bits;   // [12:0] rainflow stack tail, [25:13] stack head, [27:26] sign of the last SOC slope
-                   // (0 none, 1 up, 2 down), [31] sticky "target_soc = 0.9" flag (quirk Q7)
+                   // (0 none, 1 up, 2 down), [30] There at the current time row (carried so the step needs no
+                   // table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
 #define HOT_TAIL(b) ((int)((b) & 0x1FFFu))
 #define HOT_HEAD(b) ((int)(((b) >> 13) & 0x1FFFu))
 #define HOT_SGN(b) ((int)(((b) >> 26) & 3u))
+#define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define HOT_PACK(tail, head, sgn, t090) \
-  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((t090) ? 0x80000000u : 0u))
+#define HOT_PACK(tail, head, sgn, there, t090) \
+  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((uint32_t)(there) << 30) | ((t090) ? 0x80000000u : 0u))
 
 // Env record, 16 B.
 struct EnvRec {
@@ -73,11 +77,16 @@ struct EnvRec {
   int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
 };
 
+// Top of the rainflow reversal stack of (env e, EV c), 16 B: loaded with the hot record in rainflow mode so that
+// pushing a reversal point needs no dependent memory round trip.
+struct RfTop {
+  double s1;  // stack[tail-2]
+  double s2;  // stack[tail-1]
+};
+
 // planes of the per-(env,EV) float64 cold state, each [E*N]
 enum ColdPlane {
-  CP_S1 = 0,      // rainflow stack[tail-2] cache
-  CP_S2,          // rainflow stack[tail-1] cache
-  CP_MEAN_SUM,    // sum of cycle means over the closed cycles of this episode
+  CP_MEAN_SUM = 0,  // sum of cycle means over the closed cycles of this episode
   CP_CSUM,        // stress sum of the closed cycles with index >= rainflow_length-1
   CP_FD_CYC,      // RainflowSeiDegradation.fd_cyc
   CP_FD_CAL,      // .fd_cal
@@ -114,8 +123,8 @@ struct FleetDev {
   int tail_stride;  // floats per tail row (tail_a then tail_b, padded to a multiple of 4)
   int aux, normalize, is_caretaker, deg_mode, auto_reset;
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
-  double dt, p_avail, init_cap, eta_c, eta_d, variable_multiplier, one_minus_fee, penalty_invalid, penalty_oc, clip_oc,
-      target_soc, target_soc_lunch, eps, fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left;
+  double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
+      fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
   // ---- read-only tables ---------------------------------------------------------------------------------
   const TabRec* tab;          // [T,N]
   const AuxRec* tab_aux;      // [T,N] or nullptr when !aux
@@ -123,8 +132,10 @@ struct FleetDev {
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]
   const FleetCold* cold;
+  const struct FleetDev* self;  // device-resident copy of this block: the out-of-line rare paths read it from memory
   // ---- state ------------------------------------------------------------------------------------------
   HotRec* hot;        // [E,N]
+  RfTop* rf_top;      // [E,N] (rainflow mode)
   EnvRec* env;        // [E]
   double* cold_f;     // [CP_COUNT][E*N]
   int32_t* cold_i;    // [CI_COUNT][E*N]

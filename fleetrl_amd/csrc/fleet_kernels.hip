@@ -96,11 +96,36 @@ __device__ __forceinline__ double overloading_penalty(double rel, double scale) 
 // ---------------------------------------------------------------------------------------------------------
 // observation assembly (observer_*.py + normalization/*.py); layout: DESIGN.md "Observation row"
 // ---------------------------------------------------------------------------------------------------------
-// Per-EV slots of EV c at table row t.  soc / hours_left come from live state; the five auxiliary slots from the
-// TABLE row (quirk Q10) -- pre-assembled on the host for the configured target SOC (AuxRec), recomputed here only
-// for an EV whose target has been raised to 0.9 (quirk Q7).
-__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, size_t ti, double soc, float hl,
-                                             bool t090, const TabRec& tb) {
+// Auxiliary slots of an EV whose target SOC has been raised to 0.9 (quirk Q7): computed on the fly
+// (observer_bl_pv.py:85-91, oracle_normalization.py:127-131).  Rare, kept out of line.
+__device__ __forceinline__ void write_obs_aux_raised_target(const FleetDev& d, float* __restrict__ a, int c, const TabRec& tb) {
+  const int N = d.N;
+  const FleetCold* cd = d.cold;
+  const double th = (double)tb.there;
+  const double tgt_th = 0.9 * th;
+  const double cl = tgt_th - tb.sor;
+  const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
+  double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
+  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
+  if (cd->normalize) {
+    a[N + c] = (float)(tgt_th / cd->max_soc);
+    a[2 * N + c] = (float)(cl / cd->max_soc);
+    a[3 * N + c] = (float)(hn / cd->max_hours_needed);
+    a[4 * N + c] = (float)(lax / cd->max_laxity);
+  } else {
+    a[N + c] = (float)tgt_th;
+    a[2 * N + c] = (float)cl;
+    a[3 * N + c] = (float)hn;
+    a[4 * N + c] = (float)lax;
+  }
+}
+
+// Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the
+// step advanced to (quirk Q10) -- pre-assembled on the host for the configured target SOC (AuxRec `ar`, loaded
+// by the caller together with the table record), recomputed here only for an EV whose target has been raised to
+// 0.9 (quirk Q7).
+__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
+                                             const TabRec& tb, const AuxRec& ar) {
   const int N = d.N;
   row[c] = (float)soc;
   row[N + c] = d.normalize ? (float)((double)hl / d.max_time_left) : hl;
@@ -108,30 +133,12 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   float* a = row + 2 * N + d.tail_a_len;
   a[c] = (float)tb.there;
   if (!t090) {
-    const AuxRec ar = d.tab_aux[ti];
     a[N + c] = ar.tgt_th;
     a[2 * N + c] = ar.cl;
     a[3 * N + c] = ar.hn;
     a[4 * N + c] = ar.lax;
   } else {
-    const FleetCold* cd = d.cold;
-    const double th = (double)tb.there;
-    const double tgt_th = 0.9 * th;
-    const double cl = tgt_th - tb.sor;
-    const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
-    double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
-    lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-    if (cd->normalize) {
-      a[N + c] = (float)(tgt_th / cd->max_soc);
-      a[2 * N + c] = (float)(cl / cd->max_soc);
-      a[3 * N + c] = (float)(hn / cd->max_hours_needed);
-      a[4 * N + c] = (float)(lax / cd->max_laxity);
-    } else {
-      a[N + c] = (float)tgt_th;
-      a[2 * N + c] = (float)cl;
-      a[3 * N + c] = (float)hn;
-      a[4 * N + c] = (float)lax;
-    }
+    write_obs_aux_raised_target(*d.self, a, c, tb);
   }
 }
 
@@ -148,45 +155,84 @@ __device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restr
 // ---------------------------------------------------------------------------------------------------------
 // battery degradation
 // ---------------------------------------------------------------------------------------------------------
-// stress of one rainflow cycle: deg_rate_cycle(dod, avg_soc, temp) (rainflow_sei_degradation.py:68-80) for
-// effective_dod = clip(range*count, 0, 1) (:170)
-__device__ __forceinline__ double cycle_stress(double rng, double mean, double count, double stress_temp) {
-  double eff = rng * count;
-  eff = eff < 0.0 ? 0.0 : (eff > 1.0 ? 1.0 : eff);
-  const double s_dod = 1.0 / (1.4E5 * pow(eff, -5.01E-1) + -1.23E5);
-  const double s_soc = exp(1.04 * (mean - 0.5));
-  return s_dod * s_soc * stress_temp;
+// exp(z) for |z| <= 0.55 by its Taylor polynomial (degree 14: truncation < 2e-15 relative).  Used where the
+// argument range is known a priori, instead of the general (and far longer) library exp.
+__device__ __forceinline__ double exp_small(double z) {
+  double r = 1.0 / 87178291200.0;  // 1/14!
+  r = fma(r, z, 1.0 / 6227020800.0);
+  r = fma(r, z, 1.0 / 479001600.0);
+  r = fma(r, z, 1.0 / 39916800.0);
+  r = fma(r, z, 1.0 / 3628800.0);
+  r = fma(r, z, 1.0 / 362880.0);
+  r = fma(r, z, 1.0 / 40320.0);
+  r = fma(r, z, 1.0 / 5040.0);
+  r = fma(r, z, 1.0 / 720.0);
+  r = fma(r, z, 1.0 / 120.0);
+  r = fma(r, z, 1.0 / 24.0);
+  r = fma(r, z, 1.0 / 6.0);
+  r = fma(r, z, 0.5);
+  r = fma(r, z, 1.0);
+  r = fma(r, z, 1.0);
+  return r;
 }
 
-__device__ __forceinline__ double stress_temperature(double temp) {
-  return exp(6.93E-2 * (temp - 25.0) * ((25.0 + 273.15) / (temp + 273.15)));
+// x^(-0.501) for 0 < x <= 1, as x^(-1/2) * exp(-0.001 * ln x):
+//   x^(-1/2): hardware reciprocal-square-root seed + two Newton steps (full float64 accuracy);
+//   ln x    : hardware float32 log2 (relative error ~1e-7, i.e. <= 4e-6 absolute for x >= 1e-17); multiplied by
+//             0.001 that leaves <= 4e-9 relative error in the result; exp of an argument <= 0.04 by Taylor.
+// The library pow() would be exact to 1 ulp but costs several hundred instructions inside a divergent branch.
+__device__ __forceinline__ double pow_m0501(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  const double lnx = (double)(__builtin_amdgcn_logf((float)x)) * 0.6931471805599453;  // log2 -> ln
+  const double z = -0.001 * lnx;
+  double r = 1.0 / 720.0;
+  r = fma(r, z, 1.0 / 120.0);
+  r = fma(r, z, 1.0 / 24.0);
+  r = fma(r, z, 1.0 / 6.0);
+  r = fma(r, z, 0.5);
+  r = fma(r, z, 1.0);
+  r = fma(r, z, 1.0);
+  return y * r;
+}
+
+// stress of one rainflow cycle: deg_rate_cycle(dod, avg_soc, temp) (rainflow_sei_degradation.py:68-80) for
+// effective_dod = clip(range*count, 0, 1) (:170).  Relative accuracy ~1e-8 (see pow_m0501), which moves SoH by
+// < 1e-12 relative (the degradation is a 1e-5-sized correction to 1.0); DESIGN.md "Numerics".
+__device__ __forceinline__ double cycle_stress(double rng, double mean, double count, double stress_temp) {
+  double eff = rng * count;
+  eff = eff > 1.0 ? 1.0 : eff;
+  if (!(eff > 0.0)) return 0.0;  // pow(0, -0.501) = inf -> 1/inf = 0
+  const double s_dod = 1.0 / (1.4E5 * pow_m0501(eff) + -1.23E5);   // (kd1 * dod**kd2 + kd3) ** -1
+  const double s_soc = exp_small(1.04 * (mean - 0.5));              // e ** (k_sigma * (soc - sigma_ref)), |arg| <= 0.55
+  return s_dod * s_soc * stress_temp;
 }
 
 // A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
 // three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
-// Stack column `stk` (row stride EN); its top two entries are cached in the CP_S1/CP_S2 planes.
-__device__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& head, uint32_t& err) {
+// Stack column `stk` (row stride EN); its top two entries travel in registers (`top`, from the RfTop record).
+__device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& head, RfTop& top, uint32_t& err) {
   const size_t EN = (size_t)d.E * d.N;
   double* stk = d.rf_stack + i;
-  double* cf = d.cold_f + i;
-  int32_t* ci = d.cold_i + i;
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
-  double a = cf[(size_t)CP_S1 * EN], b = cf[(size_t)CP_S2 * EN];  // stack[tail-2], stack[tail-1]
+  double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
   stk[(size_t)tail * EN] = p;
   tail += 1;
   int size = tail - head;  // >= 2: the episode's first sample is always on the stack
   if (size >= 3 && !(fabs(p - b) < fabs(b - a))) {
+    double* cf = d.cold_f + i;
+    int32_t* ci = d.cold_i + i;
     const int L = ci[(size_t)CI_RF_LEN * EN];
     int nc = ci[(size_t)CI_NC * EN];
     double mean_sum = cf[(size_t)CP_MEAN_SUM * EN], csum = cf[(size_t)CP_CSUM * EN];
-    const double st = stress_temperature(d.cold->temperature);
     while (size >= 3) {
       const double X = fabs(p - b), Y = fabs(b - a);
       if (X < Y) break;
-      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, st);
+      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.stress_temp);
       mean_sum += 0.5 * (a + b);
       nc += 1;
       if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
@@ -204,23 +250,27 @@ __device__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& h
     cf[(size_t)CP_MEAN_SUM * EN] = mean_sum;
     cf[(size_t)CP_CSUM * EN] = csum;
   }
-  cf[(size_t)CP_S1 * EN] = b;  // stack[tail-2]
-  cf[(size_t)CP_S2 * EN] = p;  // stack[tail-1]
+  top.s1 = b;  // stack[tail-2]
+  top.s2 = p;  // stack[tail-1]
 }
 
 // RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
 // `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
-__device__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, uint32_t& err) {
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, const RfTop& top, uint32_t& err) {
   const size_t EN = (size_t)d.E * d.N;
   const double* stk = d.rf_stack + i;
   double* cf = d.cold_f + i;
   int32_t* ci = d.cold_i + i;
   const FleetCold* cd = d.cold;
+  // everything this needs from memory is requested up front (one round trip)
   const int L = ci[(size_t)CI_RF_LEN * EN];
   const int nc = ci[(size_t)CI_NC * EN];
-  const double st = stress_temperature(cd->temperature);
+  const double mean_sum0 = cf[(size_t)CP_MEAN_SUM * EN], csum0 = cf[(size_t)CP_CSUM * EN], fd_cyc0 = cf[(size_t)CP_FD_CYC * EN],
+               sei_l0 = cf[(size_t)CP_SEI_L * EN], sei_soh0 = cf[(size_t)CP_SEI_SOH * EN];
+  const double dt_hours = cd->dt;
+  const double st = d.stress_temp;
 
   int nv = 0;
   double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
@@ -240,7 +290,7 @@ __device__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
     int vt = tail, vh = head;
     int size = vt - vh + 1;
-    double a = cf[(size_t)CP_S1 * EN], b = cf[(size_t)CP_S2 * EN];
+    double a = top.s1, b = top.s2;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -266,27 +316,28 @@ __device__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int
   }
 
   double degradation = 0.0;
+  double sei_l = sei_l0;
   const int len = nc + nv;
   if (len > 0 && len > L) {
     if (max_dod > 5.0) err |= FLEET_DEVERR_DOD_RANGE;
-    const double battery_age = (double)(n - 1) * cd->dt * 3600.0;  // max(End) is always the last sample's index
-    const double mean_soc_cal = (cf[(size_t)CP_MEAN_SUM * EN] + vmean) / (double)len;
-    const double fd_cyc = cf[(size_t)CP_FD_CYC * EN] + (cf[(size_t)CP_CSUM * EN] + vsum);
+    const double battery_age = (double)(n - 1) * dt_hours * 3600.0;  // max(End) is always the last sample's index
+    const double mean_soc_cal = (mean_sum0 + vmean) / (double)len;
+    const double fd_cyc = fd_cyc0 + (csum0 + vsum);
     const double fd_cal = (4.14E-10 * battery_age) * exp(1.04 * (mean_soc_cal - 0.5)) * st;
     const double fd = fd_cyc + fd_cal;
     const double alpha = 5.75E-2, beta = 121.0;
-    const double new_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
-    if (new_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
-    degradation = new_l - cf[(size_t)CP_SEI_L * EN];
+    sei_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
+    if (sei_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
+    degradation = sei_l - sei_l0;
     cf[(size_t)CP_FD_CYC * EN] = fd_cyc;
     cf[(size_t)CP_FD_CAL * EN] = fd_cal;
-    cf[(size_t)CP_SEI_L * EN] = new_l;
+    cf[(size_t)CP_SEI_L * EN] = sei_l;
     ci[(size_t)CI_RF_LEN * EN] = len;
     cf[(size_t)CP_CSUM * EN] = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
   }
-  const double s = cf[(size_t)CP_SEI_SOH * EN] - degradation;
+  const double s = sei_soh0 - degradation;
   cf[(size_t)CP_SEI_SOH * EN] = s;
-  if (fabs(s - (1.0 - cf[(size_t)CP_SEI_L * EN])) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
+  if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
 }
 
@@ -309,7 +360,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
 template <int G>
-__device__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& r, float* __restrict__ obs_row) {
+__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& r, float* __restrict__ obs_row) {
   const int N = d.N;
   const size_t EN = (size_t)d.E * N;
   const FleetCold* cd = d.cold;
@@ -320,6 +371,8 @@ __device__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& 
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
     const TabRec tb = d.tab[ti];
+    AuxRec ar = {0.f, 0.f, 0.f, 0.f};
+    if (d.aux) ar = d.tab_aux[ti];
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
@@ -335,17 +388,19 @@ __device__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& 
     h.soc_deg = soc_deg;
     h.soh = soh;
     h.hl = hl;
-    h.bits = HOT_PACK(1, 0, 0, t090);  // rainflow: the first sample is the first reversal point
+    h.bits = HOT_PACK(1, 0, 0, tb.there, t090);  // rainflow: the first sample is the first reversal point
     d.hot[i] = h;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
       d.rf_stack[i] = soc_deg;
-      d.cold_f[(size_t)CP_S1 * EN + i] = 0.0;
-      d.cold_f[(size_t)CP_S2 * EN + i] = soc_deg;
+      RfTop top;
+      top.s1 = 0.0;
+      top.s2 = soc_deg;
+      d.rf_top[i] = top;
       d.cold_f[(size_t)CP_MEAN_SUM * EN + i] = 0.0;
       d.cold_f[(size_t)CP_CSUM * EN + i] = 0.0;
       d.cold_i[(size_t)CI_NC * EN + i] = 0;
     }
-    if (obs_row) write_obs_ev(d, obs_row, c, ti, soc, hl, t090, tb);
+    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
   }
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
   if (leader) {
@@ -372,22 +427,34 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// the step (FleetEnv.step, fleet_environment.py:436-702), K consecutive steps per launch
+// the step (FleetEnv.step, fleet_environment.py:436-702)
+//   MULTI = false: exactly one step per launch (the drop-in path: an observation is needed before the next action)
+//   MULTI = true : K consecutive steps per launch from an action tape (open-loop rollouts); waves advance
+//                  independently, so there is no per-step grid-wide synchronisation at all.
+// For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
+// wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG>
-__global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
+template <int G, int DEG, bool MULTI>
+__global__ __launch_bounds__(kBlock, 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
   const int N = d.N;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
-  const int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  if (G == 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
   const bool env_ok = e_raw < d.E;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
   const int e = env_ok ? e_raw : d.E - 1;
   const size_t EN = (size_t)d.E * N;
 
   EnvRec r = d.env[e];
+  if (G == 64) {
+    r.t = __builtin_amdgcn_readfirstlane(r.t);
+    r.t_end = __builtin_amdgcn_readfirstlane(r.t_end);
+    r.nsamp = __builtin_amdgcn_readfirstlane(r.nsamp);
+    r.episodes = __builtin_amdgcn_readfirstlane(r.episodes);
+  }
   double ep_return = 0.0, penalty_record = 0.0;
   int ep_len = 0;
   if (leader) {
@@ -400,8 +467,9 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
   int n_done = 0;
   float* const obs_row = obs + (size_t)e * d.obs_dim;
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
+  const int steps = MULTI ? K : 1;
 
-  for (int k = 0; k < K; ++k) {
+  for (int k = 0; k < steps; ++k) {
     const int t = r.t;
     int t1 = t + 1;  // :508
     if (t1 > d.T - 1) { t1 = d.T - 1; err |= FLEET_DEVERR_TABLE_END; }
@@ -411,66 +479,64 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
     float* const step_row = resets ? term_row : obs_row;
     const bool write_step_obs = env_ok && (step_row != nullptr);
 
-    const PhysRow ph = d.tab_phys[t];
-    const uint32_t flags1 = d.tab_flags[t1];
+    // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
+    const PhysRow ph = d.tab_phys[t];  // wave-uniform for G == 64: one scalar load of the 64-byte row
+    const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     const size_t abase = ((size_t)k * d.E + e) * N;
+    const TabRec* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
+    const AuxRec* __restrict__ aux_t1 = d.tab_aux + (size_t)t1 * N;
 
-    double cost = 0.0, rev = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0;
+    double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0;
     for (int c = g; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
-      const size_t ti1 = (size_t)t1 * N + c;
+      // all loads of this EV are issued before anything is consumed
       HotRec h = d.hot[i];
-      const TabRec tb1 = d.tab[ti1];
-      const uint32_t th = d.tab[(size_t)t * N + c].there;
+      RfTop top = {0.0, 0.0};
+      if (DEG == FLEET_DEG_RAINFLOW) top = d.rf_top[i];
       const double a = act_f64 ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
+      const TabRec tb1 = tab_t1[c];
+      AuxRec ar = {0.f, 0.f, 0.f, 0.f};
+      if (d.aux) ar = aux_t1[c];
+
+      const uint32_t th = HOT_THERE(h.bits);  // There at the current time row, carried from the previous step / reset
       double soc = h.soc;
       float hl = h.hl;
       const double cap = h.soh * d.init_cap;
       bool t090 = HOT_T090(h.bits);
       const double tgt = t090 ? 0.9 : d.target_soc;
+      const bool present = (th == 1u);
 
-      // ---- EvCharger.charge (ev_charger.py:89-222) ---------------------------------------------------------
-      if (a >= 0.0) {
-        const double need = (tgt - soc) * cap;    // :100
-        const double dem = d.p_avail * a * d.dt;  // :101
-        if (dem * d.eta_c > need) {               // :104-107 (applied whether or not the EV is there, quirk Q9)
-          const double x = dem - need;
-          double pen = d.penalty_oc * (x * x);
-          pen = pen > d.clip_oc ? pen : d.clip_oc;
-          rew += pen;
-        }
-        double en;
-        if (th == 1u) {
-          const double lim = need / d.eta_c;  // :114
-          en = lim < dem ? lim : dem;
-        } else {
-          en = 0.0;
-          if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :120-122
-        }
-        soc = soc + en * d.eta_c / cap;  // :128
+      // ---- EvCharger.charge (ev_charger.py:89-222), both action signs in one select-based flow -------------------
+      const bool pos = (a >= 0.0);
+      const double dem = d.p_avail * a * d.dt;   // demanded (dis)charge energy :101 / :162
+      const double need = (tgt - soc) * cap;     // ev_total_energy_demand :100
+      const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
+      {
+        // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
+        // :165-167 (needs presence, not clipped)
+        const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
+        const double x = pos ? (dem - need) : (left - dem);
+        double pen = d.penalty_oc * (x * x);
+        if (pos) pen = pen > d.clip_oc ? pen : d.clip_oc;
+        if (viol) rew += pen;
+      }
+      const double lim = need / d.eta_c;  // :114
+      double en = pos ? (lim < dem ? lim : dem) : (left > dem ? left : dem);  // :114 / :174
+      if (!present) {
+        en = 0.0;
+        if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :120-122 / :180-182
+      }
+      soc = soc + (pos ? en * d.eta_c : en) / cap;  // :128 / :189
+      if (pos) {
         double grid_e = en - ph.pv_share;  // :142
         grid_e = grid_e > 0.0 ? grid_e : 0.0;
-        cost += grid_e * ph.spot_plus_offset * d.variable_multiplier;  // :149
-        rew += ph.k_charge * grid_e;                                   // :154-156
+        cash -= grid_e * ph.k_cost;     // charging_cost :149
+        rew += ph.k_charge * grid_e;    // :154-156
       } else {
-        const double left = -1.0 * soc * cap;     // :161
-        const double dem = d.p_avail * a * d.dt;  // :162
-        if ((dem * d.eta_d < left) && (th != 0u)) {  // :165-167 (no clip, needs presence)
-          const double x = left - dem;
-          rew += d.penalty_oc * (x * x);
-        }
-        double en;
-        if (th == 1u) {
-          en = left > dem ? left : dem;  // :174
-        } else {
-          en = 0.0;
-          if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :180-182
-        }
-        soc = soc + en / cap;                                                // :189
-        rev += -1.0 * en * d.eta_d * ph.tariff / 1000.0 * d.one_minus_fee;   // :196-199
-        rew += ph.k_discharge * en;                                          // :204-206
+        cash += en * ph.k_rev;          // discharging_revenue :196-199
+        rew += ph.k_discharge * en;     // :204-206
       }
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
@@ -498,7 +564,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
 
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
-      if (write_step_obs) write_obs_ev(d, step_row, c, ti1, soc, hl, t090, tb1);
+      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
 
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       int tail = HOT_TAIL(h.bits), head = HOT_HEAD(h.bits), sgn = HOT_SGN(h.bits);
@@ -508,10 +574,13 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
         // the previous sample a reversal point
         if (soc_deg != old_deg) {
           const int s_next = (soc_deg > old_deg) ? 1 : 2;
-          if (sgn != 0 && sgn != s_next) rf_push(d, i, old_deg, tail, head, err);
+          if (sgn != 0 && sgn != s_next) {
+            rf_push(d, i, old_deg, tail, head, top, err);
+            d.rf_top[i] = top;
+          }
           sgn = s_next;
         }
-        if (deg_row) soh = soh - sei_evaluate(d, i, soc_deg, r.nsamp + 1, tail, head, err);  // :666-671
+        if (deg_row) soh = soh - sei_evaluate(*d.self, i, soc_deg, r.nsamp + 1, tail, head, top, err);  // :666-671
       }
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
@@ -520,7 +589,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
         h.soc_deg = soc_deg;
         h.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
         h.hl = hl;
-        h.bits = HOT_PACK(tail, head, sgn, t090);
+        h.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
         d.hot[i] = h;
       }
     }
@@ -528,14 +597,12 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
-    cost = group_sum_to_last<G>(cost);
-    rev = group_sum_to_last<G>(rev);
+    cash = group_sum_to_last<G>(cash);
     rew = group_sum_to_last<G>(rew);
     asum = group_sum_to_last<G>(asum);
-    penrec = group_sum_to_last<G>(penrec);
+    if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
     r.t = t1;
     if (leader) {
-      const double cashflow = -1.0 * cost + rev;  // ev_charger.py:225
       penalty_record += penrec;
       // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
       const double head_room = d.grid_connection - ph.load - asum * d.evse_power + ph.pv;
@@ -549,8 +616,8 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       ep_len += 1;
       reward_sum += rew;
       if (env_ok) {
-        d.env_f[(size_t)EF_CASHFLOW * d.E + e] = cashflow;
-        if (K == 1) {
+        d.env_f[(size_t)EF_CASHFLOW * d.E + e] = cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
+        if (!MULTI) {
           reward[e] = rew;
           done[e] = is_done ? 1 : 0;
         }
@@ -566,7 +633,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
       r.episodes += 1;
       if (resets) {
         if (env_ok) {
-          reset_env<G>(d, e, g, leader, r, obs_row);
+          reset_env<G>(*d.self, e, g, leader, r, obs_row);
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = r.t + d.episode_steps;
@@ -584,7 +651,7 @@ __global__ __launch_bounds__(kBlock, 2) void fleet_step_kernel(FleetDev d, const
     d.env_f[(size_t)EF_EP_RETURN * d.E + e] = ep_return;
     d.env_i[(size_t)EI_EP_LEN * d.E + e] = ep_len;
     d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e] = penalty_record;
-    if (K != 1) {
+    if (MULTI) {
       reward[e] = reward_sum;
       if (done_count) done_count[e] = n_done;
     }
@@ -649,8 +716,13 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
-  hipLaunchKernelGGL((fleet_step_kernel<G, DEG>), grid, block, 0, s, d, actions, act_dtype == FLEET_ACT_F64 ? 1 : 0, K, obs,
-                     reward, done, terminal_obs, done_count);
+  const int f64 = act_dtype == FLEET_ACT_F64 ? 1 : 0;
+  if (K == 1 && !done_count)
+    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false>), grid, block, 0, s, d, actions, f64, 1, obs, reward, done,
+                       terminal_obs, done_count);
+  else
+    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true>), grid, block, 0, s, d, actions, f64, K, obs, reward, done,
+                       terminal_obs, done_count);
   return hipGetLastError();
 }
 
