@@ -1,0 +1,21 @@
+"""Synthetic workload generator: structural invariants the step relies on."""
+import numpy as np
+
+from fleetrl_amd.synth import synth_tables
+
+
+def test_synth_tables_are_consistent():
+    tb = synth_tables("ct", 6, seed=5)
+    assert tb.T == 365 * 96 and tb.N == 6
+    assert set(np.unique(tb.there)) <= {0, 1}
+    assert tb.meta["time_left_exact"]
+    away = tb.there == 0
+    assert np.all(tb.time_left[away] == 0) and np.all(tb.soc_on_return[away] == 0)
+    assert np.all(np.mod(tb.time_left, 0.25) == 0)
+    home = tb.there == 1
+    assert tb.soc_on_return[home].min() > 0 and tb.soc_on_return.max() <= 0.85
+    assert not np.isnan(tb.delu).any() and not np.isnan(tb.prc).any()
+    # different vehicles get different schedules (the reference generator seeds them identically)
+    assert not np.array_equal(tb.there[:, 0], tb.there[:, 1])
+    tb2 = synth_tables("ct", 6, seed=5)
+    assert np.array_equal(tb.there, tb2.there) and np.array_equal(tb.soc_on_return, tb2.soc_on_return)

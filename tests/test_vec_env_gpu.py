@@ -1,0 +1,115 @@
+"""The drop-in Python surface on the GPU: return types/shapes/dtypes of the reference's FleetEnv, the SB3 VecEnv
+contract (auto-reset, terminal_observation, env_method) and the gymnasium vector signature.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from golden_util import load_trace, params_for
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_signature_and_values_match_the_reference():
+    """FleetEnv.reset()/step() return exactly what the reference returns (fleet_environment.py:434, :702)."""
+    from fleetrl_amd import FleetEnv
+
+    g = load_trace("lmd1_price_linear")
+    env = FleetEnv(g.cfg, tables=g.tables, start_rows=g.starts[:, :1], extrema=g.extrema, start_range=(0, 0))
+    assert env.observation_space.shape == (int(g.sc_obs_dim),) and env.observation_space.dtype == np.float32
+    assert env.action_space.shape == (g.N,) and float(env.action_space.low.min()) == -1 and float(env.action_space.high.max()) == 1
+    assert np.isinf(env.observation_space.low).all()
+    obs, info = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float32 and obs.shape == (int(g.sc_obs_dim),) and info == {}
+    np.testing.assert_array_equal(obs, g.reset_obs[0, 0])
+    for k in range(g.ep_steps):
+        out = env.step(g.actions[0, k])
+        assert len(out) == 5
+        o, r, d, tr, inf = out
+        assert isinstance(r, float) and isinstance(d, bool) and tr is False and inf == {}
+        assert o.dtype == np.float32
+        np.testing.assert_allclose(o, g.obs[0, k], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r, g.reward[0, k], rtol=1e-9, atol=1e-12)
+        assert d == bool(g.done[0, k])
+        assert env.is_done() == d
+    assert d is True
+    # gymnasium.Env semantics: no auto-reset, the last observation is the terminal one
+    np.testing.assert_allclose(o, g.terminal_obs[0, 0], rtol=1e-5, atol=1e-6)
+    obs, _ = env.reset()
+    np.testing.assert_array_equal(obs, g.reset_obs[0, 1])
+    np.testing.assert_allclose(env.get_dist_factor(), g.dist_factor[0, 1], rtol=1e-12)
+    assert str(env.get_time()) == str(env.get_start_time())
+    env.close()
+
+
+def test_sb3_vec_env_contract_against_a_sequential_oracle_loop():
+    from fleetrl_amd import FleetVecEnv
+    from oracle.fleet_oracle import OracleBatch
+
+    g = load_trace("ct5_both_rainflow")
+    E = 6
+    rng = np.random.default_rng(3)
+    starts = rng.integers(0, g.tables.T - g.ep_steps - 60, size=(2, E)).astype(np.int32)
+    venv = FleetVecEnv(g.cfg, E, tables=g.tables, start_rows=starts, extrema=g.extrema, start_range=(0, 0))
+    ora = OracleBatch(venv.core.params, g.tables, g.time_feat)
+    ora.set_start_schedule(starts)
+    assert venv.num_envs == E and venv.env_is_wrapped(object) == [False] * E
+    obs = venv.reset()
+    np.testing.assert_array_equal(obs, ora.reset())
+    n_done = 0
+    for s in range(g.ep_steps + 5):
+        a = rng.uniform(-0.3, 1, size=(E, g.N)).astype(np.float32)
+        venv.step_async(a)
+        obs, rew, dones, infos = venv.step_wait()
+        o2, r2, d2, t2 = ora.step(a)
+        assert obs.dtype == np.float32 and rew.dtype == np.float32 and dones.dtype == bool and len(infos) == E
+        np.testing.assert_array_equal(dones, d2.astype(bool))
+        np.testing.assert_allclose(obs, o2, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rew, r2.astype(np.float32), rtol=1e-6, atol=1e-6)
+        for i in range(E):
+            if dones[i]:
+                n_done += 1
+                np.testing.assert_allclose(infos[i]["terminal_observation"], t2[i], rtol=1e-5, atol=1e-6)
+                assert infos[i]["episode"]["l"] == g.ep_steps and infos[i]["TimeLimit.truncated"] is False
+            else:
+                assert infos[i] == {}
+    assert n_done == E
+    # env_method fan-out (fleet_environment.py:741-799)
+    assert venv.env_method("is_done") == [False] * E
+    t = venv.env_method("get_time")
+    assert len(t) == E and str(t[0]) == str(g.tables.dates[ora.get("time_idx")[0]]).replace("T", " ")
+    np.testing.assert_allclose(np.array(venv.env_method("get_dist_factor", indices=[1, 3])), ora.dist_factor()[[1, 3]], rtol=1e-12)
+    venv.env_method("set_start_time", "2020-03-01 00:00", indices=0)
+    assert venv.env_method("get_start_time", indices=0) == ["2020-03-01 00:00"]
+    assert venv.env_method("get_log")[0] is None
+    with pytest.raises(AttributeError):
+        venv.env_method("no_such_method")
+    venv.close()
+
+
+def test_gymnasium_vector_signature_and_torch_path():
+    import torch
+
+    from fleetrl_amd import FleetVecEnv, FleetVectorEnv
+
+    g = load_trace("lmd5_price_linear")
+    E = 9
+    starts = np.full((1, E), 10, dtype=np.int32)
+    v1 = FleetVectorEnv(g.cfg, E, tables=g.tables, start_rows=starts, extrema=g.extrema, start_range=(0, 0))
+    v2 = FleetVecEnv(g.cfg, E, tables=g.tables, start_rows=starts, extrema=g.extrema, start_range=(0, 0))
+    o1, info = v1.reset(seed=123)
+    o2 = v2.reset()
+    assert info == {} and np.array_equal(o1, o2)
+    assert v1.observation_space.shape == (E, v1.core.obs_dim) and v1.action_space.shape == (E, g.N)
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda", 0)
+    for s in range(g.ep_steps):
+        a = rng.uniform(-1, 1, size=(E, g.N)).astype(np.float32)
+        obs, rew, term, trunc, infos = v1.step(a)
+        ot, rt, dt = v2.step_torch(torch.from_numpy(a).to(dev))
+        v2.core.batch.synchronize()
+        assert term.dtype == bool and not trunc.any() and rew.dtype == np.float64
+        np.testing.assert_array_equal(obs, ot.cpu().numpy())
+        np.testing.assert_array_equal(rew, rt.cpu().numpy())
+        np.testing.assert_array_equal(term, dt.cpu().numpy().astype(bool))
+    assert term.all() and infos["_final_observation"].all() and infos["final_observation"][0].shape == (v1.core.obs_dim,)
+    v1.close()
+    v2.close()
