@@ -315,27 +315,33 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
 
   // ---- state ----------------------------------------------------------------------------------------
   const size_t EN = (size_t)E * N;
-  if ((rc = dev_alloc(b, &d.hot, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.hot_a, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.hot_b, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.sei, EN))) return rc;
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
-  if ((rc = dev_alloc(b, &d.cold_f, EN * CP_COUNT))) return rc;
-  if ((rc = dev_alloc(b, &d.cold_i, EN * CI_COUNT))) return rc;
   if ((rc = dev_alloc(b, &d.env_f, (size_t)E * EF_COUNT))) return rc;
   if ((rc = dev_alloc(b, &d.env_i, (size_t)E * EI_COUNT))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
-    if ((rc = dev_alloc(b, &d.rf_stack, EN * (size_t)d.stack_cap, false))) return rc;
+    d.rf_row_stride = ((4 + d.stack_cap + 15) / 16) * 16;  // RfAcc header + stack, rounded to whole 128-byte lines
+    if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
     if ((rc = dev_alloc(b, &d.rf_top, EN))) return rc;
+    // RfAcc headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
+    RfAcc acc0;
+    acc0.mean_sum = 0; acc0.csum = 0; acc0.nc = 0; acc0.rf_len = 1; acc0.pad = 0;
+    std::vector<RfAcc> accs(EN, acc0);
+    HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, accs.data(), sizeof(RfAcc), sizeof(RfAcc), EN,
+                                hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
   {
     // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66), the initial
     // SoH and the (cleared) sticky target flags (fleet_environment.py:263)
-    std::vector<HotRec> hot(EN);
-    for (auto& h : hot) { h.soc = 0; h.soc_deg = 0; h.soh = p->init_soh; h.hl = 0; h.bits = 0; }
-    std::vector<double> soh(EN, p->init_soh), l(EN, 1.0 - p->init_soh);
-    std::vector<int32_t> one(EN, 1);
-    HIP_TRY(b, hipMemcpyAsync(d.hot, hot.data(), EN * sizeof(HotRec), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.cold_f + (size_t)CP_SEI_SOH * EN, soh.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.cold_f + (size_t)CP_SEI_L * EN, l.data(), EN * 8, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(b, hipMemcpyAsync(d.cold_i + (size_t)CI_RF_LEN * EN, one.data(), EN * 4, hipMemcpyHostToDevice, b->stream));
+    std::vector<HotB> hb(EN);
+    for (auto& h : hb) { h.soh = p->init_soh; h.hl = 0; h.bits = 0; }
+    std::vector<SeiRec> sei(EN);
+    for (auto& q : sei) { q.fd_cyc = 0; q.fd_cal = 0; q.sei_soh = p->init_soh; q.sei_l = 1.0 - p->init_soh; }
+    HIP_TRY(b, hipMemcpyAsync(d.hot_b, hb.data(), EN * sizeof(HotB), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.sei, sei.data(), EN * sizeof(SeiRec), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
   // device-resident copy of the argument block for the out-of-line rare paths (reset, daily degradation)

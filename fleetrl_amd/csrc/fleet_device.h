@@ -2,8 +2,8 @@
 // (fleet_kernels.hip) and the host side of the C ABI (fleet_capi.hip).  gfx950 only.
 //
 // Layout rules (DESIGN.md "Data layout in HBM"):
-//   * everything a lane touches every step sits in ONE 32-byte record per (env, EV)  -> two 16-byte loads/stores
-//     per lane, consecutive lanes = consecutive records (a wavefront of a 50-EV env moves one 1600-byte run);
+//   * everything a lane touches every step sits in two 16-byte half-records per (env, EV), each in its own array:
+//     one 16-byte load/store per lane and half, consecutive lanes = consecutive records, whole cache lines;
 //   * everything a group needs per env and step sits in ONE 16-byte record (broadcast load);
 //   * table values of (time row, EV) sit in 16-byte records, the env-level observation blocks and the physics
 //     scalars of a time row in contiguous rows;
@@ -51,10 +51,13 @@ struct AuxRec {
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
 // ---- state ---------------------------------------------------------------------------------------------------
-// Hot record of (env e, EV c), 32 B.
-struct HotRec {
+// Hot state of (env e, EV c): two 16-byte halves kept in two arrays, so that every wave-level load / store of a
+// half covers whole cache lines (a 32-byte AoS record written 24 bytes at a time costs two partial writes per line).
+struct HotA {
   double soc;      // episode.soc
   double soc_deg;  // episode.soc_deg == last logged SOC sample (LogDataDeg.soc_log[-1])
+};
+struct HotB {
   double soh;      // episode.soh  (battery_cap = soh * init_battery_cap is recomputed on use)
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
   uint32_t bits;   // [12:0] rainflow stack tail, [25:13] stack head, [27:26] sign of the last SOC slope
@@ -84,18 +87,22 @@ struct RfTop {
   double s2;  // stack[tail-1]
 };
 
-// planes of the per-(env,EV) float64 cold state, each [E*N]
-enum ColdPlane {
-  CP_MEAN_SUM = 0,  // sum of cycle means over the closed cycles of this episode
-  CP_CSUM,        // stress sum of the closed cycles with index >= rainflow_length-1
-  CP_FD_CYC,      // RainflowSeiDegradation.fd_cyc
-  CP_FD_CAL,      // .fd_cal
-  CP_SEI_L,       // .l
-  CP_SEI_SOH,     // .soh (the model's own copy, only used by its consistency check)
-  CP_COUNT
+// Rainflow accumulators of (env e, EV c), 32 B, touched only when a cycle closes and on the daily row: one record =
+// one cache line per event (separate planes cost one line per field).
+struct RfAcc {
+  double mean_sum;  // sum of cycle means over the closed cycles of this episode
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1
+  int32_t nc;       // closed cycles this episode
+  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
+  double pad;
 };
-// planes of the per-(env,EV) int32 cold state
-enum ColdIPlane { CI_NC = 0 /* closed cycles this episode */, CI_RF_LEN /* rainflow_length */, CI_COUNT };
+// SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
+struct SeiRec {
+  double fd_cyc;   // RainflowSeiDegradation.fd_cyc
+  double fd_cal;   // .fd_cal
+  double sei_l;    // .l
+  double sei_soh;  // .soh (the model's own copy, only used by its consistency check)
+};
 // planes of the per-env float64 / int32 statistics
 enum EnvFPlane { EF_EP_RETURN = 0, EF_LAST_EP_RETURN, EF_CASHFLOW, EF_PENALTY_RECORD, EF_COUNT };
 enum EnvIPlane { EI_START = 0, EI_EP_LEN, EI_LAST_EP_LEN, EI_ERR, EI_DONE, EI_COUNT };
@@ -134,14 +141,17 @@ struct FleetDev {
   const FleetCold* cold;
   const struct FleetDev* self;  // device-resident copy of this block: the out-of-line rare paths read it from memory
   // ---- state ------------------------------------------------------------------------------------------
-  HotRec* hot;        // [E,N]
+  HotA* hot_a;        // [E,N]
+  HotB* hot_b;        // [E,N]
   RfTop* rf_top;      // [E,N] (rainflow mode)
+  SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
-  double* cold_f;     // [CP_COUNT][E*N]
-  int32_t* cold_i;    // [CI_COUNT][E*N]
   double* env_f;      // [EF_COUNT][E]
   int32_t* env_i;     // [EI_COUNT][E]
-  double* rf_stack;   // [stack_cap][E*N] reversal stack of the streaming rainflow (time-major: lanes stay coalesced)
+  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfAcc (4 doubles) followed by the reversal stack, EV-major
+                      // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators + the
+                      // stack entries around the top) instead of one line per field / stack level
+  int rf_row_stride;  // doubles per row (multiple of 16)
 };
 
 // launchers implemented in fleet_kernels.hip

@@ -213,22 +213,21 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
 // three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
 // Stack column `stk` (row stride EN); its top two entries travel in registers (`top`, from the RfTop record).
 __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& head, RfTop& top, uint32_t& err) {
-  const size_t EN = (size_t)d.E * d.N;
-  double* stk = d.rf_stack + i;
+  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+  double* stk = row + 4;  // the stack follows the RfAcc header in the same 128-byte-aligned row
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
   double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
-  stk[(size_t)tail * EN] = p;
+  stk[tail] = p;
   tail += 1;
   int size = tail - head;  // >= 2: the episode's first sample is always on the stack
   if (size >= 3 && !(fabs(p - b) < fabs(b - a))) {
-    double* cf = d.cold_f + i;
-    int32_t* ci = d.cold_i + i;
-    const int L = ci[(size_t)CI_RF_LEN * EN];
-    int nc = ci[(size_t)CI_NC * EN];
-    double mean_sum = cf[(size_t)CP_MEAN_SUM * EN], csum = cf[(size_t)CP_CSUM * EN];
+    RfAcc acc = *reinterpret_cast<RfAcc*>(row);
+    const int L = acc.rf_len;
+    int nc = acc.nc;
+    double mean_sum = acc.mean_sum, csum = acc.csum;
     while (size >= 3) {
       const double X = fabs(p - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -241,14 +240,15 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
       } else {  // full cycle, drop its two points -> stack = [..., p]
         tail -= 2;
         size -= 2;
-        stk[(size_t)(tail - 1) * EN] = p;
-        b = stk[(size_t)(tail - 2) * EN];                       // size >= 2 here
-        a = (size >= 3) ? stk[(size_t)(tail - 3) * EN] : 0.0;
+        stk[tail - 1] = p;
+        b = stk[tail - 2];                       // size >= 2 here
+        a = (size >= 3) ? stk[tail - 3] : 0.0;
       }
     }
-    ci[(size_t)CI_NC * EN] = nc;
-    cf[(size_t)CP_MEAN_SUM * EN] = mean_sum;
-    cf[(size_t)CP_CSUM * EN] = csum;
+    acc.nc = nc;
+    acc.mean_sum = mean_sum;
+    acc.csum = csum;
+    *reinterpret_cast<RfAcc*>(row) = acc;
   }
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
@@ -259,16 +259,15 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
 __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, const RfTop& top, uint32_t& err) {
-  const size_t EN = (size_t)d.E * d.N;
-  const double* stk = d.rf_stack + i;
-  double* cf = d.cold_f + i;
-  int32_t* ci = d.cold_i + i;
+  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+  const double* stk = row + 4;
   const FleetCold* cd = d.cold;
   // everything this needs from memory is requested up front (one round trip)
-  const int L = ci[(size_t)CI_RF_LEN * EN];
-  const int nc = ci[(size_t)CI_NC * EN];
-  const double mean_sum0 = cf[(size_t)CP_MEAN_SUM * EN], csum0 = cf[(size_t)CP_CSUM * EN], fd_cyc0 = cf[(size_t)CP_FD_CYC * EN],
-               sei_l0 = cf[(size_t)CP_SEI_L * EN], sei_soh0 = cf[(size_t)CP_SEI_SOH * EN];
+  RfAcc acc = *reinterpret_cast<RfAcc*>(row);
+  SeiRec sr = d.sei[i];
+  const int L = acc.rf_len;
+  const int nc = acc.nc;
+  const double mean_sum0 = acc.mean_sum, csum0 = acc.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
   const double dt_hours = cd->dt;
   const double st = d.stress_temp;
 
@@ -301,14 +300,14 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
       } else {
         vt -= 2;
         size -= 2;
-        b = stk[(size_t)(vt - 1) * EN];
-        a = (size >= 3) ? stk[(size_t)(vt - 2) * EN] : 0.0;
+        b = stk[vt - 1];
+        a = (size >= 3) ? stk[vt - 2] : 0.0;
       }
     }
     // remaining ranges are half cycles: stack[vh..vt) followed by the forced point
-    double prev = (vt - vh >= 2) ? stk[(size_t)vh * EN] : b;
+    double prev = (vt - vh >= 2) ? stk[vh] : b;
     for (int j = vh + 1; j < vt; ++j) {
-      const double cur = (j == vt - 1) ? b : stk[(size_t)j * EN];
+      const double cur = (j == vt - 1) ? b : stk[j];
       emit(prev, cur, 0.5);
       prev = cur;
     }
@@ -329,14 +328,16 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     sei_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
     if (sei_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
     degradation = sei_l - sei_l0;
-    cf[(size_t)CP_FD_CYC * EN] = fd_cyc;
-    cf[(size_t)CP_FD_CAL * EN] = fd_cal;
-    cf[(size_t)CP_SEI_L * EN] = sei_l;
-    ci[(size_t)CI_RF_LEN * EN] = len;
-    cf[(size_t)CP_CSUM * EN] = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
+    sr.fd_cyc = fd_cyc;
+    sr.fd_cal = fd_cal;
+    sr.sei_l = sei_l;
+    acc.rf_len = len;
+    acc.csum = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
+    *reinterpret_cast<RfAcc*>(row) = acc;
   }
   const double s = sei_soh0 - degradation;
-  cf[(size_t)CP_SEI_SOH * EN] = s;
+  sr.sei_soh = s;
+  d.sei[i] = sr;
   if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
 }
@@ -373,7 +374,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const TabRec tb = d.tab[ti];
     AuxRec ar = {0.f, 0.f, 0.f, 0.f};
     if (d.aux) ar = d.tab_aux[ti];
-    const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
+    const bool t090 = HOT_T090(d.hot_b[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
     double soc = tb.sor;
@@ -383,22 +384,27 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    HotRec h;
-    h.soc = soc;
-    h.soc_deg = soc_deg;
-    h.soh = soh;
-    h.hl = hl;
-    h.bits = HOT_PACK(1, 0, 0, tb.there, t090);  // rainflow: the first sample is the first reversal point
-    d.hot[i] = h;
+    HotA ha;
+    ha.soc = soc;
+    ha.soc_deg = soc_deg;
+    HotB hb;
+    hb.soh = soh;
+    hb.hl = hl;
+    hb.bits = HOT_PACK(1, 0, 0, tb.there, t090);  // rainflow: the first sample is the first reversal point
+    d.hot_a[i] = ha;
+    d.hot_b[i] = hb;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      d.rf_stack[i] = soc_deg;
+      double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
       RfTop top;
       top.s1 = 0.0;
       top.s2 = soc_deg;
       d.rf_top[i] = top;
-      d.cold_f[(size_t)CP_MEAN_SUM * EN + i] = 0.0;
-      d.cold_f[(size_t)CP_CSUM * EN + i] = 0.0;
-      d.cold_i[(size_t)CI_NC * EN + i] = 0;
+      RfAcc acc = *reinterpret_cast<RfAcc*>(row);  // rainflow_length survives
+      acc.mean_sum = 0.0;
+      acc.csum = 0.0;
+      acc.nc = 0;
+      *reinterpret_cast<RfAcc*>(row) = acc;
+      row[4] = soc_deg;
     }
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
   }
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI>
-__global__ __launch_bounds__(kBlock, 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
+__global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
@@ -492,19 +498,27 @@ __global__ __launch_bounds__(kBlock, 4) void fleet_step_kernel(FleetDev d, const
     for (int c = g; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
-      HotRec h = d.hot[i];
+      const HotA ha = d.hot_a[i];
+      const HotB hb = d.hot_b[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = d.rf_top[i];
       const double a = act_f64 ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       const TabRec tb1 = tab_t1[c];
       AuxRec ar = {0.f, 0.f, 0.f, 0.f};
       if (d.aux) ar = aux_t1[c];
+      // Rainflow: a present EV with a non-zero action will most likely change its SOC slope bookkeeping this step;
+      // touch its rainflow row now so that the (divergent, dependent) accesses of a push / cycle closure later hit
+      // the cache instead of paying a memory round trip each.
+      double rf_touch = 0.0;
+      if (DEG == FLEET_DEG_RAINFLOW) {
+        if (HOT_THERE(hb.bits) && a != 0.0 && HOT_SGN(hb.bits) != 0) rf_touch = d.rf_rows[i * (size_t)d.rf_row_stride];
+      }
 
-      const uint32_t th = HOT_THERE(h.bits);  // There at the current time row, carried from the previous step / reset
-      double soc = h.soc;
-      float hl = h.hl;
-      const double cap = h.soh * d.init_cap;
-      bool t090 = HOT_T090(h.bits);
+      const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
+      double soc = ha.soc;
+      float hl = hb.hl;
+      const double cap = hb.soh * d.init_cap;
+      bool t090 = HOT_T090(hb.bits);
       const double tgt = t090 ? 0.9 : d.target_soc;
       const bool present = (th == 1u);
 
@@ -559,38 +573,39 @@ __global__ __launch_bounds__(kBlock, 4) void fleet_step_kernel(FleetDev d, const
         hl = ntl;
         soc = tb1.sor;
       }
-      if (h.soh <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
-      const double old_deg = h.soc_deg;
+      if (hb.soh <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
+      const double old_deg = ha.soc_deg;
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
 
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
       if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
 
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      int tail = HOT_TAIL(h.bits), head = HOT_HEAD(h.bits), sgn = HOT_SGN(h.bits);
-      double soh = h.soh;
+      int tail = HOT_TAIL(hb.bits), head = HOT_HEAD(hb.bits), sgn = HOT_SGN(hb.bits);
+      double soh = hb.soh;
       if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
         // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes
         // the previous sample a reversal point
         if (soc_deg != old_deg) {
           const int s_next = (soc_deg > old_deg) ? 1 : 2;
-          if (sgn != 0 && sgn != s_next) {
-            rf_push(d, i, old_deg, tail, head, top, err);
-            d.rf_top[i] = top;
-          }
+          if (sgn != 0 && sgn != s_next) rf_push(d, i, old_deg, tail, head, top, err);
           sgn = s_next;
         }
-        if (deg_row) soh = soh - sei_evaluate(*d.self, i, soc_deg, r.nsamp + 1, tail, head, top, err);  // :666-671
       }
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
-      if (env_ok) {
-        h.soc = soc;
-        h.soc_deg = soc_deg;
-        h.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
-        h.hl = hl;
-        h.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
-        d.hot[i] = h;
+      if (DEG == FLEET_DEG_RAINFLOW) asm volatile("" ::"v"(rf_touch));  // keep the touch load alive
+      if (env_ok) {  // whole 16-byte records, always: dense full-line stores
+        HotA na;
+        na.soc = soc;
+        na.soc_deg = soc_deg;
+        HotB nb;
+        nb.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
+        nb.hl = hl;
+        nb.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
+        d.hot_a[i] = na;
+        d.hot_b[i] = nb;
+        if (DEG == FLEET_DEG_RAINFLOW) d.rf_top[i] = top;
       }
     }
     if (write_step_obs) write_obs_tail<G>(d, step_row, t1, g);
@@ -621,6 +636,20 @@ __global__ __launch_bounds__(kBlock, 4) void fleet_step_kernel(FleetDev d, const
           reward[e] = rew;
           done[e] = is_done ? 1 : 0;
         }
+      }
+    }
+    // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
+    // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
+    // (transcendentals, accumulators) never coexist with the hot path's registers; the few words it needs are re-read
+    // from the records this lane has just stored.  One step in 96, and wave-uniform for G == 64.
+    if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
+      for (int c = g; c < N; c += G) {
+        const size_t i = (size_t)e * N + c;
+        HotB hb = d.hot_b[i];
+        const double sample = d.hot_a[i].soc_deg;
+        const RfTop top = d.rf_top[i];
+        hb.soh = hb.soh - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err);
+        d.hot_b[i] = hb;
       }
     }
     if (is_done) {
@@ -666,7 +695,7 @@ __global__ void fleet_dist_factor_kernel(FleetDev d, double* __restrict__ out) {
   const int e = (int)(i / d.N), c = (int)(i % d.N);
   const TabRec tb = d.tab[(size_t)d.env[e].t * d.N + c];
   const double th = (double)tb.there;
-  const double tgt = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc;
+  const double tgt = HOT_T090(d.hot_b[i].bits) ? 0.9 : d.target_soc;
   const double cl = tgt * th - tb.sor;
   const double hn = cl * d.cold->batt_cap_nominal / d.cold->hn_denominator;
   out[i] = hn / ((double)tb.tl + 0.001);
@@ -681,15 +710,17 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
                        field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
-    case FLEET_F_SOC: ((double*)out)[i] = d.hot[i].soc; break;
-    case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot[i].hl; break;
-    case FLEET_F_SOH: ((double*)out)[i] = d.hot[i].soh; break;
-    case FLEET_F_SOC_DEG: ((double*)out)[i] = d.hot[i].soc_deg; break;
-    case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc; break;
-    case FLEET_F_RF_LEN: ((int32_t*)out)[i] = d.cold_i[(size_t)CI_RF_LEN * EN + i]; break;
-    case FLEET_F_FD_CYC: ((double*)out)[i] = d.cold_f[(size_t)CP_FD_CYC * EN + i]; break;
-    case FLEET_F_FD_CAL: ((double*)out)[i] = d.cold_f[(size_t)CP_FD_CAL * EN + i]; break;
-    case FLEET_F_SEI_L: ((double*)out)[i] = d.cold_f[(size_t)CP_SEI_L * EN + i]; break;
+    case FLEET_F_SOC: ((double*)out)[i] = d.hot_a[i].soc; break;
+    case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot_b[i].hl; break;
+    case FLEET_F_SOH: ((double*)out)[i] = d.hot_b[i].soh; break;
+    case FLEET_F_SOC_DEG: ((double*)out)[i] = d.hot_a[i].soc_deg; break;
+    case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot_b[i].bits) ? 0.9 : d.target_soc; break;
+    case FLEET_F_RF_LEN:
+      ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfAcc*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;
+      break;
+    case FLEET_F_FD_CYC: ((double*)out)[i] = d.sei[i].fd_cyc; break;
+    case FLEET_F_FD_CAL: ((double*)out)[i] = d.sei[i].fd_cal; break;
+    case FLEET_F_SEI_L: ((double*)out)[i] = d.sei[i].sei_l; break;
     case FLEET_F_TIME_IDX: ((int32_t*)out)[i] = d.env[i].t; break;
     case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env_i[(size_t)EI_START * E + i]; break;
     case FLEET_F_CASHFLOW: ((double*)out)[i] = d.env_f[(size_t)EF_CASHFLOW * E + i]; break;
