@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return lib_path()
     csrc = os.path.join(_HERE, "csrc")
-    cmd = [hipcc(), *FLAGS, *[os.path.join(csrc, s) for s in SOURCES], "-o", lib_path()]
+    extra = os.environ.get("FLEET_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics only (ablation builds)
+    cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(csrc, s) for s in SOURCES], "-o", lib_path()]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])

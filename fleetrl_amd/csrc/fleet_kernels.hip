@@ -204,6 +204,9 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
   double eff = rng * count;
   eff = eff > 1.0 ? 1.0 : eff;
   if (!(eff > 0.0)) return 0.0;  // pow(0, -0.501) = inf -> 1/inf = 0
+#ifdef FLEET_ABL_NO_STRESS
+  return eff * mean * stress_temp;
+#endif
   const double s_dod = 1.0 / (1.4E5 * pow_m0501(eff) + -1.23E5);   // (kd1 * dod**kd2 + kd3) ** -1
   const double s_soc = exp_small(1.04 * (mean - 0.5));              // e ** (k_sigma * (soc - sigma_ref)), |arg| <= 0.55
   return s_dod * s_soc * stress_temp;
@@ -511,7 +514,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       // the cache instead of paying a memory round trip each.
       double rf_touch = 0.0;
       if (DEG == FLEET_DEG_RAINFLOW) {
+#ifdef FLEET_ENABLE_RF_TOUCH
         if (HOT_THERE(hb.bits) && a != 0.0 && HOT_SGN(hb.bits) != 0) rf_touch = d.rf_rows[i * (size_t)d.rf_row_stride];
+#endif
       }
 
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
@@ -578,7 +583,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
 
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
+#ifndef FLEET_ABL_NO_OBS
       if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
+#endif
 
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       int tail = HOT_TAIL(hb.bits), head = HOT_HEAD(hb.bits), sgn = HOT_SGN(hb.bits);
@@ -588,7 +595,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
         // the previous sample a reversal point
         if (soc_deg != old_deg) {
           const int s_next = (soc_deg > old_deg) ? 1 : 2;
+#ifndef FLEET_ABL_NO_PUSH
           if (sgn != 0 && sgn != s_next) rf_push(d, i, old_deg, tail, head, top, err);
+#endif
           sgn = s_next;
         }
       }
@@ -608,7 +617,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
         if (DEG == FLEET_DEG_RAINFLOW) d.rf_top[i] = top;
       }
     }
+#ifndef FLEET_ABL_NO_OBS
     if (write_step_obs) write_obs_tail<G>(d, step_row, t1, g);
+#endif
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
@@ -642,7 +653,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers; the few words it needs are re-read
     // from the records this lane has just stored.  One step in 96, and wave-uniform for G == 64.
+#ifdef FLEET_ABL_NO_EVAL
+    if (false) {
+#else
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
+#endif
       for (int c = g; c < N; c += G) {
         const size_t i = (size_t)e * N + c;
         HotB hb = d.hot_b[i];

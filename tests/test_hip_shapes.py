@@ -1,0 +1,100 @@
+"""HIP product vs the CPU oracle on seeded synthetic inputs across group geometries (N = 1 ... 200 EVs: one lane per
+env up to several EVs per lane), ragged batch sizes, all degradation modes and normalisation, with auto-reset over
+several episodes.  Needs an MI355X.  Bar: flags/indices bit-exact, float32 obs <= 1e-5 rel, float64 state <= 1e-9 rel."""
+import numpy as np
+import pytest
+
+from fleetrl_amd.config import resolve_config
+from fleetrl_amd.params import make_params, time_features
+from fleetrl_amd.synth import synth_tables
+
+pytestmark = pytest.mark.gpu
+
+_TABLES = {}
+
+
+def _tables(uc, n):
+    if (uc, n) not in _TABLES:
+        _TABLES[(uc, n)] = synth_tables(uc, n, seed=100 + n)
+    return _TABLES[(uc, n)]
+
+
+def _cfg(uc, deg, norm, aux=True, building=True, pv=True, episode_length=24):
+    return {
+        "data_path": "<synthetic>", "use_case": uc, "building_name": None, "price_name": None, "tariff_name": None,
+        "schedule_name": None, "pv_name": None, "seed": 0, "include_building": building, "include_pv": pv,
+        "include_price": True, "time_picker": "random", "max_batt_cap_in_all_use_cases": 60, "init_soh": 1.0,
+        "log_data": False, "deg_emp": deg == "linear", "calculate_degradation": deg != "none", "verbose": 0,
+        "normalize_in_env": norm, "aux": aux, "ignore_price_reward": False, "ignore_overloading_penalty": False,
+        "ignore_invalid_penalty": False, "ignore_overcharging_penalty": False, "gen_schedule": False,
+        "gen_start_date": None, "gen_end_date": None, "gen_name": None, "gen_n_evs": 1, "spot_markup": None,
+        "spot_mul": None, "feed_in_ded": None, "real_time": False, "episode_length": episode_length, "target_soc": 0.85,
+    }
+
+
+def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=True, seed=0):
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+
+    tb = _tables(uc, n_evs)
+    rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv))
+    p = make_params(rc, tb, num_envs, seed=seed + 1)
+    tf = time_features(tb)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=4)
+    rng = np.random.default_rng(seed)
+    np.testing.assert_array_equal(hip.reset(), cpu.reset())
+    np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))  # same Philox start rows
+    n_done = 0
+    for s in range(steps):
+        mode = (s // 40) % 3
+        a = rng.uniform(-1, 1, size=(num_envs, n_evs)) if mode == 0 else rng.uniform(-0.2, 1, size=(num_envs, n_evs)) \
+            if mode == 1 else np.full((num_envs, n_evs), 1.0)
+        a[rng.random(a.shape) < 0.15] = 0.0
+        a = a.astype(np.float32)
+        oh, rh, dh, th = hip.step(a)
+        oc, rc_, dc, tc = cpu.step(a)
+        np.testing.assert_array_equal(dh, dc, err_msg=f"done, step {s}")
+        np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6, err_msg=f"obs, step {s}")
+        np.testing.assert_allclose(rh, rc_, rtol=1e-9, atol=1e-9, err_msg=f"reward, step {s}")
+        if dh.any():
+            n_done += int(dh.sum())
+            np.testing.assert_allclose(th[dh.astype(bool)], tc[dc.astype(bool)], rtol=1e-5, atol=1e-6)
+        if s % 16 == 0 or s == steps - 1:
+            np.testing.assert_array_equal(hip.get("time_idx"), cpu.get("time_idx"))
+            np.testing.assert_array_equal(hip.get("hours_left"), cpu.get("hours_left"))
+            np.testing.assert_allclose(hip.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(hip.get("soh"), cpu.get("soh"), rtol=1e-9)
+            np.testing.assert_allclose(hip.get("cashflow"), cpu.get("cashflow"), rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(hip.get("ep_return"), cpu.get("ep_return"), rtol=1e-9, atol=1e-8)
+            if deg == "rainflow":
+                np.testing.assert_array_equal(hip.get("rf_len"), cpu.get("rf_len"))
+                np.testing.assert_allclose(hip.get("fd_cyc"), cpu.get("fd_cyc"), rtol=1e-6, atol=1e-15)
+                np.testing.assert_allclose(hip.get("sei_l"), cpu.get("sei_l"), rtol=1e-7, atol=1e-15)
+    hip.check_errors()
+    assert not cpu.get("error_bits").any()
+    np.testing.assert_array_equal(hip.get("episodes"), cpu.get("episodes"))
+    np.testing.assert_allclose(hip.get("last_ep_return"), cpu.get("last_ep_return"), rtol=1e-9, atol=1e-8)
+    assert n_done >= num_envs  # every env went through at least one auto-reset
+    hip.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("n_evs,num_envs", [(1, 130), (2, 67), (3, 50), (7, 41), (16, 33), (31, 9), (64, 6), (70, 5), (200, 3)])
+def test_group_geometries_rainflow(n_evs, num_envs):
+    _compare("lmd", n_evs, num_envs, "rainflow", False, steps=200)
+
+
+@pytest.mark.parametrize("deg,norm", [("none", True), ("linear", False), ("linear", True), ("rainflow", True)])
+def test_degradation_and_normalisation_modes(deg, norm):
+    _compare("ut", 12, 37, deg, norm, steps=200)
+
+
+@pytest.mark.parametrize("aux,building,pv,norm", [(False, False, False, False), (True, True, False, True), (True, False, True, False),
+                                                  (False, True, True, True)])
+def test_observer_variants(aux, building, pv, norm):
+    _compare("ct", 5, 19, "rainflow", norm, steps=120, aux=aux, building=building, pv=pv)
+
+
+def test_headline_shape_slice():
+    """50 EVs per env (one wavefront per env), caretaker fleet, load+pv, rainflow: the bench workload at 96 envs."""
+    _compare("ct", 50, 96, "rainflow", False, steps=220)
