@@ -206,6 +206,12 @@ def main():
             batch.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rsum.data_ptr())
         many_ms = batch.timer_stop()
         batch.check_errors()
+        # HBM traffic of the step kernel from the committed rocprofv3 PMC passes of this same command
+        # (tools/prof_traffic.sh -> profiles/r01_traffic_step_kernel.json); null when the workload differs from the profiled one
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_step_kernel.json")
+        if os.path.isfile(tpath) and (E, N, args.use_case, args.deg) == (4096, 50, "ct", "rainflow"):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -219,7 +225,7 @@ def main():
                        "envs_per_gpu": E, "evs_per_env": N, "obs_dim": batch.obs_dim, "launch": "hipGraph" if use_graph else "eager",
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "fleet_step_kernel<64,2,float>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_env_step": bytes_step, "bytes_per_launch": bytes_step * E,
                          "stream_ms_per_step_incl_gaps": ev_ms / args.steps},
             "step_many": {"K": K, "env_steps_per_s": E * K * reps / (many_ms * 1e-3),

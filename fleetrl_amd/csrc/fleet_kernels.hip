@@ -477,6 +477,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
   float* const obs_row = obs + (size_t)e * d.obs_dim;
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
   const int steps = MULTI ? K : 1;
+  const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
 
   for (int k = 0; k < steps; ++k) {
     const int t = r.t;
@@ -489,7 +490,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     const bool write_step_obs = env_ok && (step_row != nullptr);
 
     // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
-    const PhysRow ph = d.tab_phys[t];  // wave-uniform for G == 64: one scalar load of the 64-byte row
+    // The 64-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
+    // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
+    const PhysRow ph = d.tab_phys[t + vzero];
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
