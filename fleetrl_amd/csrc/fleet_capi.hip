@@ -215,20 +215,21 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
   for (int r = 0; r < T; ++r) phys[r].flags_next = flags[r + 1 < T ? r + 1 : T - 1];
 }
 
-// Per-(t, EV) records: the three schedule columns packed into 16 bytes, and the five auxiliary observation
+// Per-(t, EV) records (32 bytes): the three schedule columns packed into 16 bytes, and the five auxiliary observation
 // slots pre-assembled for the configured target SOC (observer_bl_pv.py:85-91 and, when normalising,
 // oracle_normalization.py:127-131) -- float64 in the reference's operation order, stored as the float32 words the
 // reference would emit.  `there` is kept in TabRec; the other four go to AuxRec.
-void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabRec>& tab, std::vector<AuxRec>& aux) {
+void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabX>& tab) {
   const size_t TN = (size_t)p.table_rows * p.num_cars;
   tab.resize(TN);
-  if (p.aux) aux.resize(TN);
   const bool norm = p.normalize != 0;
   const double hn_den = p.evse_power * p.charging_eff;
   for (size_t k = 0; k < TN; ++k) {
-    tab[k].sor = t.soc_on_return[k];
-    tab[k].tl = t.time_left[k];
-    tab[k].there = t.there[k];
+    TabX& x = tab[k];
+    x.tb.sor = t.soc_on_return[k];
+    x.tb.tl = t.time_left[k];
+    x.tb.there = t.there[k];
+    x.ar.tgt_th = x.ar.cl = x.ar.hn = x.ar.lax = 0.0f;
     if (!p.aux) continue;
     const double th = (double)t.there[k];
     const double tgt_th = p.target_soc * th;
@@ -236,11 +237,10 @@ void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabRe
     const double hn = cl * p.batt_cap_nominal / hn_den;
     double lax = ((double)t.time_left[k] / (hn + 0.001) - 1) * th;
     lax = lax < 0 ? 0 : (lax > 5 ? 5 : lax);
-    AuxRec& a = aux[k];
-    a.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
-    a.cl = (float)(norm ? cl / p.max_soc : cl);
-    a.hn = (float)(norm ? hn / p.max_hours_needed : hn);
-    a.lax = (float)(norm ? lax / p.max_laxity : lax);
+    x.ar.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
+    x.ar.cl = (float)(norm ? cl / p.max_soc : cl);
+    x.ar.hn = (float)(norm ? hn / p.max_hours_needed : hn);
+    x.ar.lax = (float)(norm ? lax / p.max_laxity : lax);
   }
 }
 
@@ -299,11 +299,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     build_phys_rows(*p, *t, phys, flags);
     std::vector<float> tail;
     build_tail_rows(*p, *t, d.tail_a_len, d.tail_b_len, d.tail_stride, tail);
-    std::vector<TabRec> tab;
-    std::vector<AuxRec> aux;
-    build_ev_rows(*p, *t, tab, aux);
+    std::vector<TabX> tab;
+    build_ev_rows(*p, *t, tab);
     if ((rc = dev_upload(b, &d.tab, tab.data(), tab.size()))) return rc;
-    if (p->aux && (rc = dev_upload(b, &d.tab_aux, aux.data(), aux.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
@@ -319,8 +317,6 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &d.hot_b, EN))) return rc;
   if ((rc = dev_alloc(b, &d.sei, EN))) return rc;
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
-  if ((rc = dev_alloc(b, &d.env_f, (size_t)E * EF_COUNT))) return rc;
-  if ((rc = dev_alloc(b, &d.env_i, (size_t)E * EI_COUNT))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
     d.rf_row_stride = ((4 + d.stack_cap + 15) / 16) * 16;  // RfAcc header + stack, rounded to whole 128-byte lines
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;

@@ -47,6 +47,12 @@ struct AuxRec {
   float lax;     // laxity
 };
 
+// What a lane reads of (time row t, EV c): both records side by side, 32 B, one array / one pointer.
+struct TabX {
+  TabRec tb;
+  AuxRec ar;  // zeros when the auxiliary observations are off
+};
+
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
@@ -72,12 +78,25 @@ struct HotB {
 #define HOT_PACK(tail, head, sgn, there, t090) \
   ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((uint32_t)(there) << 30) | ((t090) ? 0x80000000u : 0u))
 
-// Env record, 16 B.
-struct EnvRec {
+// Env record, 64 B = one cache line: the 16-byte head every lane of the group needs (wave-uniform for G == 64),
+// followed by the episode statistics only the group's leader lane touches.  One pointer, one line per env and step
+// (separate planes cost a pointer pair and a cache line each).
+struct EnvHead {
   int32_t t;         // current table row (episode.time)
-  int32_t t_end;     // finish row (episode.finish_time)
+  int32_t t_end;     // finish row (episode.finish_time); the start row is t_end - episode_steps
   int32_t nsamp;     // len(LogDataDeg.soc_log)
   int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
+};
+struct EnvRec {
+  EnvHead h;
+  int32_t ep_len;          // steps taken in the running episode
+  int32_t last_ep_len;     // length of the last finished episode
+  uint32_t err;            // FLEET_DEVERR_* bits
+  int32_t done;            // episode.done
+  double ep_return;        // episode.cumulative_reward
+  double last_ep_return;   // return of the last finished episode
+  double cashflow;         // episode.current_charging_expense (last step)
+  double penalty_record;   // episode.penalty_record
 };
 
 // Top of the rainflow reversal stack of (env e, EV c), 16 B: loaded with the hot record in rainflow mode so that
@@ -103,10 +122,6 @@ struct SeiRec {
   double sei_l;    // .l
   double sei_soh;  // .soh (the model's own copy, only used by its consistency check)
 };
-// planes of the per-env float64 / int32 statistics
-enum EnvFPlane { EF_EP_RETURN = 0, EF_LAST_EP_RETURN, EF_CASHFLOW, EF_PENALTY_RECORD, EF_COUNT };
-enum EnvIPlane { EI_START = 0, EI_EP_LEN, EI_LAST_EP_LEN, EI_ERR, EI_DONE, EI_COUNT };
-
 // Scalars only the rare paths need (reset, daily degradation, slow observation path).  Lives in device memory and
 // is read through a pointer so that the hot path's scalar-register budget is not spent on it.
 struct FleetCold {
@@ -133,8 +148,7 @@ struct FleetDev {
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
   // ---- read-only tables ---------------------------------------------------------------------------------
-  const TabRec* tab;          // [T,N]
-  const AuxRec* tab_aux;      // [T,N] or nullptr when !aux
+  const TabX* tab;            // [T,N]
   const PhysRow* tab_phys;    // [T]
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]
@@ -146,8 +160,6 @@ struct FleetDev {
   RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
-  double* env_f;      // [EF_COUNT][E]
-  int32_t* env_i;     // [EI_COUNT][E]
   double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfAcc (4 doubles) followed by the reversal stack, EV-major
                       // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators + the
                       // stack entries around the top) instead of one line per field / stack level

@@ -128,7 +128,7 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
                                              const TabRec& tb, const AuxRec& ar) {
   const int N = d.N;
   row[c] = (float)soc;
-  row[N + c] = d.normalize ? (float)((double)hl / d.max_time_left) : hl;
+  row[N + c] = d.normalize ? (float)((double)hl / d.self->max_time_left) : hl;
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
   a[c] = (float)tb.there;
@@ -234,7 +234,7 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
     while (size >= 3) {
       const double X = fabs(p - b), Y = fabs(b - a);
       if (X < Y) break;
-      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.stress_temp);
+      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.self->stress_temp);
       mean_sum += 0.5 * (a + b);
       nc += 1;
       if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
@@ -364,7 +364,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
 template <int G>
-__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvRec& r, float* __restrict__ obs_row) {
+__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row) {
   const int N = d.N;
   const size_t EN = (size_t)d.E * N;
   const FleetCold* cd = d.cold;
@@ -374,9 +374,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
-    const TabRec tb = d.tab[ti];
-    AuxRec ar = {0.f, 0.f, 0.f, 0.f};
-    if (d.aux) ar = d.tab_aux[ti];
+    const TabX tx = d.tab[ti];
+    const TabRec tb = tx.tb;
+    const AuxRec ar = tx.ar;
     const bool t090 = HOT_T090(d.hot_b[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
@@ -413,13 +413,13 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   }
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
   if (leader) {
-    d.env[e] = r;
-    d.env_i[(size_t)EI_START * d.E + e] = start;
-    d.env_f[(size_t)EF_EP_RETURN * d.E + e] = 0.0;
-    d.env_i[(size_t)EI_EP_LEN * d.E + e] = 0;
-    d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e] = 0.0;
-    d.env_i[(size_t)EI_DONE * d.E + e] = 0;
-    if (r.t_end > d.T - 1) atomicOr((unsigned int*)&d.env_i[(size_t)EI_ERR * d.E + e], FLEET_DEVERR_TABLE_END);
+    EnvRec* er = d.env + e;
+    er->h = r;
+    er->ep_return = 0.0;
+    er->ep_len = 0;
+    er->penalty_record = 0.0;
+    er->done = 0;
+    if (r.t_end > d.T - 1) atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
   }
 }
 
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   const int e = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (e >= d.E) return;
   if (mask && !mask[e]) return;
-  EnvRec r = d.env[e];
+  EnvHead r = d.env[e].h;
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
-  if (d.env_i[(size_t)EI_EP_LEN * d.E + e] > 0 && !d.env_i[(size_t)EI_DONE * d.E + e]) r.episodes += 1;
+  if (d.env[e].ep_len > 0 && !d.env[e].done) r.episodes += 1;
   reset_env<G>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr);
 }
 
@@ -448,6 +448,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
+#ifdef FLEET_ABL_EMPTY
+  if (d.E > 0) return;
+#endif
   const int N = d.N;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
   const int e = env_ok ? e_raw : d.E - 1;
   const size_t EN = (size_t)d.E * N;
 
-  EnvRec r = d.env[e];
+  EnvHead r = d.env[e].h;
   if (G == 64) {
     r.t = __builtin_amdgcn_readfirstlane(r.t);
     r.t_end = __builtin_amdgcn_readfirstlane(r.t_end);
@@ -467,9 +470,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
   double ep_return = 0.0, penalty_record = 0.0;
   int ep_len = 0;
   if (leader) {
-    ep_return = d.env_f[(size_t)EF_EP_RETURN * d.E + e];
-    penalty_record = d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e];
-    ep_len = d.env_i[(size_t)EI_EP_LEN * d.E + e];
+    const EnvRec* er = d.env + e;
+    ep_return = er->ep_return;
+    penalty_record = er->penalty_record;
+    ep_len = er->ep_len;
   }
   uint32_t err = 0;
   double reward_sum = 0.0;
@@ -497,8 +501,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     const size_t abase = ((size_t)k * d.E + e) * N;
-    const TabRec* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
-    const AuxRec* __restrict__ aux_t1 = d.tab_aux + (size_t)t1 * N;
+    const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
 
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0;
     for (int c = g; c < N; c += G) {
@@ -509,9 +512,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = d.rf_top[i];
       const double a = act_f64 ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
-      const TabRec tb1 = tab_t1[c];
-      AuxRec ar = {0.f, 0.f, 0.f, 0.f};
-      if (d.aux) ar = aux_t1[c];
+      const TabX tx1 = tab_t1[c];
+      const TabRec tb1 = tx1.tb;
+      const AuxRec ar = tx1.ar;
       // Rainflow: a present EV with a non-zero action will most likely change its SOC slope bookkeeping this step;
       // touch its rainflow row now so that the (divergent, dependent) accesses of a push / cycle closure later hit
       // the cache instead of paying a memory round trip each.
@@ -565,14 +568,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
-        const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
+        const double target = lunch ? d.self->target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
-        if (missing > d.eps) {
+        if (missing > d.self->eps) {
           const double pen = soc_violation_penalty(missing);
           rew += pen;
           penrec += pen;  // episode.penalty_record (:549,566,584)
         } else {
-          rew += d.fully_charged_reward;
+          rew += d.self->fully_charged_reward;
         }
       }
       if ((ntl != 0.0f) && (hl != 0.0f)) {  // still charging :593-594
@@ -634,10 +637,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     if (leader) {
       penalty_record += penrec;
       // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
-      const double head_room = d.grid_connection - ph.load - asum * d.evse_power + ph.pv;
+      const double head_room = d.self->grid_connection - ph.load - asum * d.self->evse_power + ph.pv;
       const double over = fabs(head_room < 0.0 ? head_room : 0.0);
       if (over > 0.0) {
-        const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
+        const double pen = overloading_penalty(over / d.self->grid_connection + 1.0, d.self->penalty_overload);
         rew += pen;
         penalty_record += pen;
       }
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       ep_len += 1;
       reward_sum += rew;
       if (env_ok) {
-        d.env_f[(size_t)EF_CASHFLOW * d.E + e] = cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
+        d.env[e].cashflow = cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
         if (!MULTI) {
           reward[e] = rew;
           done[e] = is_done ? 1 : 0;
@@ -673,9 +676,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     if (is_done) {
       n_done += 1;
       if (leader && env_ok) {
-        d.env_f[(size_t)EF_LAST_EP_RETURN * d.E + e] = ep_return;
-        d.env_i[(size_t)EI_LAST_EP_LEN * d.E + e] = ep_len;
-        d.env_i[(size_t)EI_DONE * d.E + e] = 1;
+        EnvRec* er = d.env + e;
+        er->last_ep_return = ep_return;
+        er->last_ep_len = ep_len;
+        er->done = 1;
       }
       r.episodes += 1;
       if (resets) {
@@ -694,16 +698,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
   }
 
   if (leader && env_ok) {
-    d.env[e] = r;
-    d.env_f[(size_t)EF_EP_RETURN * d.E + e] = ep_return;
-    d.env_i[(size_t)EI_EP_LEN * d.E + e] = ep_len;
-    d.env_f[(size_t)EF_PENALTY_RECORD * d.E + e] = penalty_record;
+    EnvRec* er = d.env + e;
+    er->h = r;
+    er->ep_return = ep_return;
+    er->ep_len = ep_len;
+    er->penalty_record = penalty_record;
     if (MULTI) {
       reward[e] = reward_sum;
       if (done_count) done_count[e] = n_done;
     }
   }
-  if (err && env_ok) atomicOr((unsigned int*)&d.env_i[(size_t)EI_ERR * d.E + e], err);
+  if (err && env_ok) atomicOr(&d.env[e].err, err);
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)
@@ -711,7 +716,7 @@ __global__ void fleet_dist_factor_kernel(FleetDev d, double* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)d.E * d.N) return;
   const int e = (int)(i / d.N), c = (int)(i % d.N);
-  const TabRec tb = d.tab[(size_t)d.env[e].t * d.N + c];
+  const TabRec tb = d.tab[(size_t)d.env[e].h.t * d.N + c].tb;
   const double th = (double)tb.there;
   const double tgt = HOT_T090(d.hot_b[i].bits) ? 0.9 : d.target_soc;
   const double cl = tgt * th - tb.sor;
@@ -739,17 +744,17 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_FD_CYC: ((double*)out)[i] = d.sei[i].fd_cyc; break;
     case FLEET_F_FD_CAL: ((double*)out)[i] = d.sei[i].fd_cal; break;
     case FLEET_F_SEI_L: ((double*)out)[i] = d.sei[i].sei_l; break;
-    case FLEET_F_TIME_IDX: ((int32_t*)out)[i] = d.env[i].t; break;
-    case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env_i[(size_t)EI_START * E + i]; break;
-    case FLEET_F_CASHFLOW: ((double*)out)[i] = d.env_f[(size_t)EF_CASHFLOW * E + i]; break;
-    case FLEET_F_EP_RETURN: ((double*)out)[i] = d.env_f[(size_t)EF_EP_RETURN * E + i]; break;
-    case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env_i[(size_t)EI_EP_LEN * E + i]; break;
-    case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env_f[(size_t)EF_LAST_EP_RETURN * E + i]; break;
-    case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env_i[(size_t)EI_LAST_EP_LEN * E + i]; break;
-    case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = (uint32_t)d.env_i[(size_t)EI_ERR * E + i]; break;
-    case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)d.env_i[(size_t)EI_DONE * E + i]; break;
-    case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].episodes; break;
-    case FLEET_F_PENALTY_RECORD: ((double*)out)[i] = d.env_f[(size_t)EF_PENALTY_RECORD * E + i]; break;
+    case FLEET_F_TIME_IDX: ((int32_t*)out)[i] = d.env[i].h.t; break;
+    case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env[i].h.t_end - d.episode_steps; break;
+    case FLEET_F_CASHFLOW: ((double*)out)[i] = d.env[i].cashflow; break;
+    case FLEET_F_EP_RETURN: ((double*)out)[i] = d.env[i].ep_return; break;
+    case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env[i].ep_len; break;
+    case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env[i].last_ep_return; break;
+    case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env[i].last_ep_len; break;
+    case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = d.env[i].err; break;
+    case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)d.env[i].done; break;
+    case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].h.episodes; break;
+    case FLEET_F_PENALTY_RECORD: ((double*)out)[i] = d.env[i].penalty_record; break;
     default: break;
   }
 }
