@@ -192,8 +192,11 @@ def main():
         tail_a = 2 * (rc.price_lookahead + 1) + 2 * (rc.bl_pv_lookahead + 1)
         bytes_step = algorithmic_bytes_per_env_step(N, batch.obs_dim, tail_a, True, S)
         # dominant kernel: fleet_step_kernel, one launch per step; per-launch duration from one HIP event pair per launch
+        # average launch duration: HIP events on the kernels' stream around the timed region (K graph-replayed launches,
+        # ~0.5 us of inter-kernel gap per launch included -> slightly conservative; rocprofv3's per-kernel average is in
+        # profiles/).  A second figure brackets every launch with its own event pair (adds ~1.5 us of event overhead).
+        k_ms = ev_ms / args.steps
         per = batch.time_steps_dev(min(args.steps, 512), tape.data_ptr(), L, obs.data_ptr(), reward.data_ptr(), done.data_ptr())
-        k_ms = float(np.mean(per))
         achieved = bytes_step * E / (k_ms * 1e-3) / 1e9
         # K-steps-per-launch entry (open-loop rollouts), reported aside
         K = 64
@@ -227,7 +230,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_env_step": bytes_step, "bytes_per_launch": bytes_step * E,
-                         "stream_ms_per_step_incl_gaps": ev_ms / args.steps},
+                         "kernel_ms_event_pair_per_launch": float(np.mean(per))},
             "step_many": {"K": K, "env_steps_per_s": E * K * reps / (many_ms * 1e-3),
                           "GBps": bytes_step * E * K * reps / (many_ms * 1e-3) / 1e9},
             "episodes_gathered": int((n_all > 0).sum().item()),

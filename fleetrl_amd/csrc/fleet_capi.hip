@@ -498,6 +498,22 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
   return FLEET_OK;
 }
 
+int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count) {
+  if (!h || K < 1 || !obs || !reward_sum ||
+      (policy != FLEET_ACT_POLICY_UNCONTROLLED && policy != FLEET_ACT_POLICY_DISTRIBUTED)) {
+    if (h) h->error = "fleet_rollout_policy_dev: bad argument";
+    return FLEET_ERR_INVALID;
+  }
+  if (!h->d.auto_reset) {
+    h->error = "fleet_rollout_policy_dev needs auto_reset = 1";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  // K >= 1 always takes the multi-step kernel (policies are only compiled into it); done_count may be NULL
+  HIP_TRY(h, fleet_launch_step(h->d, nullptr, policy, K, obs, reward_sum, h->st_done, nullptr, done_count, h->stream));
+  return FLEET_OK;
+}
+
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs) {
   if (!h || !obs) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));

@@ -4,11 +4,11 @@
 // Layout rules (DESIGN.md "Data layout in HBM"):
 //   * everything a lane touches every step sits in two 16-byte half-records per (env, EV), each in its own array:
 //     one 16-byte load/store per lane and half, consecutive lanes = consecutive records, whole cache lines;
-//   * everything a group needs per env and step sits in ONE 16-byte record (broadcast load);
-//   * table values of (time row, EV) sit in 16-byte records, the env-level observation blocks and the physics
+//   * everything a group needs per env and step sits in ONE 64-byte record (16-byte head + leader statistics);
+//   * table values of (time row, EV) sit in one 32-byte record, the env-level observation blocks and the physics
 //     scalars of a time row in contiguous rows;
-//   * rarely touched state (degradation bookkeeping) is kept in separate SoA planes so it costs nothing on the
-//     hot path.
+//   * rarely touched state (rainflow accumulators + stack, SEI model) sits in per-EV 128-byte-aligned rows / 32-byte
+//     records so an event touches one cache line and the hot path none.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

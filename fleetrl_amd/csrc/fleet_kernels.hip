@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI>
-__global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_f64, int K,
+__global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
@@ -511,7 +511,25 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       const HotB hb = d.hot_b[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = d.rf_top[i];
-      const double a = act_f64 ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
+      double a;
+      if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
+        // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
+        if (act_mode == FLEET_ACT_POLICY_UNCONTROLLED) {
+          a = 1.0;  // benchmarking/uncontrolled_charging.py:51-54: np.ones(n_evs)
+        } else {
+          // benchmarking/distributed_charging.py:50-54: clip(get_dist_factor(), 0, 1), get_dist_factor =
+          // hours_needed / (hours_left + 0.001) from the TABLE row of the current time (fleet_environment.py:782-799)
+          const TabRec tb0 = d.tab[(size_t)t * N + c].tb;
+          const FleetCold* cd = d.cold;
+          const double th0 = (double)tb0.there;
+          const double cl0 = (HOT_T090(hb.bits) ? 0.9 : d.target_soc) * th0 - tb0.sor;
+          const double hn0 = cl0 * cd->batt_cap_nominal / cd->hn_denominator;
+          const double f = hn0 / ((double)tb0.tl + 0.001);
+          a = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+        }
+      } else {
+        a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
+      }
       const TabX tx1 = tab_t1[c];
       const TabRec tb1 = tx1.tb;
       const AuxRec ar = tx1.ar;
@@ -770,8 +788,8 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
-  const int f64 = act_dtype == FLEET_ACT_F64 ? 1 : 0;
-  if (K == 1 && !done_count)
+  const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
+  if (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED)
     hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false>), grid, block, 0, s, d, actions, f64, 1, obs, reward, done,
                        terminal_obs, done_count);
   else

@@ -50,6 +50,9 @@ extern "C" {
 /* action element type */
 #define FLEET_ACT_F32 0
 #define FLEET_ACT_F64 1
+/* built-in open-loop policies (fleet_rollout_policy_dev): the action rules of the reference's benchmark harnesses */
+#define FLEET_ACT_POLICY_UNCONTROLLED 2 /* all ones           (benchmarking/uncontrolled_charging.py:51-54) */
+#define FLEET_ACT_POLICY_DISTRIBUTED 3  /* clip(get_dist_factor(), 0, 1) (benchmarking/distributed_charging.py:50-54) */
 
 /* device-side error bits (per env, OR-ed into one word; see fleet_get(FLEET_F_ERROR_BITS))               */
 #define FLEET_DEVERR_OBS_FORMAT 1u     /* the reference's `raise TypeError("Observation format not recognized")` :610 */
@@ -190,6 +193,11 @@ int fleet_step_dev(fleet_handle h, const void* actions, int act_dtype, float* ob
  * episode ends among them.  auto_reset must be 1. */
 int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtype, float* obs,
                         double* reward_sum, int32_t* done_count);
+
+/* K consecutive steps in ONE launch with a built-in policy (FLEET_ACT_POLICY_*) evaluated on the device instead of an
+ * action tape: the reference's `benchmarking/` harnesses without a host round trip per step.  Outputs as
+ * fleet_step_many_dev.  auto_reset must be 1. */
+int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count);
 
 /* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);
