@@ -551,36 +551,29 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       const double tgt = t090 ? 0.9 : d.target_soc;
       const bool present = (th == 1u);
 
-      // ---- EvCharger.charge (ev_charger.py:89-222), both action signs in one select-based flow -------------------
+      // ---- EvCharger.charge (ev_charger.py:89-222) -----------------------------------------------------------------
+      // Both action signs in ONE straight-line flow: every quantity of both branches is computed unconditionally and
+      // merged with selects / min / max, so a wavefront whose lanes hold both signs (the normal case) does not walk two
+      // masked branches, and there is no exec-mask bookkeeping on the hot path.
       const bool pos = (a >= 0.0);
       const double dem = d.p_avail * a * d.dt;   // demanded (dis)charge energy :101 / :162
       const double need = (tgt - soc) * cap;     // ev_total_energy_demand :100
       const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
-      {
-        // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
-        // :165-167 (needs presence, not clipped)
-        const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
-        const double x = pos ? (dem - need) : (left - dem);
-        double pen = d.penalty_oc * (x * x);
-        if (pos) pen = pen > d.clip_oc ? pen : d.clip_oc;
-        if (viol) rew += pen;
-      }
+      // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
+      // :165-167 (needs presence, not clipped)
+      const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
+      const double x = pos ? (dem - need) : (left - dem);
+      const double pen_raw = d.penalty_oc * (x * x);
+      const double pen_oc = pos ? fmax(pen_raw, d.clip_oc) : pen_raw;
+      rew += viol ? pen_oc : 0.0;
       const double lim = need / d.eta_c;  // :114
-      double en = pos ? (lim < dem ? lim : dem) : (left > dem ? left : dem);  // :114 / :174
-      if (!present) {
-        en = 0.0;
-        if (fabs(a) > 0.05) rew += d.penalty_invalid * (a * a);  // :120-122 / :180-182
-      }
+      const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
+      const double en = present ? en_p : 0.0;
+      rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
       soc = soc + (pos ? en * d.eta_c : en) / cap;  // :128 / :189
-      if (pos) {
-        double grid_e = en - ph.pv_share;  // :142
-        grid_e = grid_e > 0.0 ? grid_e : 0.0;
-        cash -= grid_e * ph.k_cost;     // charging_cost :149
-        rew += ph.k_charge * grid_e;    // :154-156
-      } else {
-        cash += en * ph.k_rev;          // discharging_revenue :196-199
-        rew += ph.k_discharge * en;     // :204-206
-      }
+      const double grid_e = fmax(en - ph.pv_share, 0.0);  // :142 (charging only)
+      cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
+      rew += pos ? ph.k_charge * grid_e : ph.k_discharge * en;   // :154-156 / :204-206
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
@@ -596,11 +589,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
           rew += d.self->fully_charged_reward;
         }
       }
-      if ((ntl != 0.0f) && (hl != 0.0f)) {  // still charging :593-594
-        hl = (float)((double)hl - d.dt);
-      } else {  // no car in the next step :597-599, or new arrival :602-606 (the reference's `else: raise` is unreachable)
-        hl = ntl;
-        soc = tb1.sor;
+      {
+        const bool staying = (ntl != 0.0f) && (hl != 0.0f);  // still charging :593-594; otherwise no car in the next
+        hl = staying ? (float)((double)hl - d.dt) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
+        soc = staying ? soc : tb1.sor;                       // `else: raise` is unreachable)
       }
       if (hb.soh <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
       const double old_deg = ha.soc_deg;
