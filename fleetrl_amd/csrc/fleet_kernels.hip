@@ -142,14 +142,19 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   }
 }
 
-// env-level blocks: a pure function of the table row, pre-assembled (and pre-normalised) on the host.
+// env-level blocks: a pure function of the table row, pre-assembled (and pre-normalised) on the host.  Lane j copies
+// tail float j to its slot (block A right after the 2N state slots, block B after the 5N auxiliary slots); for the
+// usual sizes (<= G floats) this is one predicated load/store per lane, no loop.
 template <int G>
 __device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restrict__ row, int t, int g) {
   const float* __restrict__ src = d.tab_tail + (size_t)t * d.tail_stride;
-  float* a = row + 2 * d.N;
-  for (int j = g; j < d.tail_a_len; j += G) a[j] = src[j];
-  float* b = row + 2 * d.N + d.tail_a_len + 5 * d.N;
-  for (int j = g; j < d.tail_b_len; j += G) b[j] = src[d.tail_a_len + j];
+  const int na = d.tail_a_len, total = d.tail_a_len + d.tail_b_len;
+  const unsigned base_a = 2u * (unsigned)d.N, base_b = 7u * (unsigned)d.N;  // block B: 2N + na + 5N + (j - na) = 7N + j
+  int j = g;
+  if (j < total) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
+  if (total > G) {
+    for (j += G; j < total; j += G) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -639,10 +644,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
+#ifndef FLEET_ABL_NO_REDUCE
     cash = group_sum_to_last<G>(cash);
     rew = group_sum_to_last<G>(rew);
     asum = group_sum_to_last<G>(asum);
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
+#endif
     r.t = t1;
     if (leader) {
       penalty_record += penrec;
