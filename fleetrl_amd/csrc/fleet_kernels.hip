@@ -584,14 +584,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
-        const double target = lunch ? d.self->target_soc_lunch : tgt;  // :536-557
+        const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
-        if (missing > d.self->eps) {
+        if (missing > d.eps) {
           const double pen = soc_violation_penalty(missing);
           rew += pen;
           penrec += pen;  // episode.penalty_record (:549,566,584)
         } else {
-          rew += d.self->fully_charged_reward;
+          rew += d.fully_charged_reward;
         }
       }
       {
@@ -654,10 +654,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     if (leader) {
       penalty_record += penrec;
       // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
-      const double head_room = d.self->grid_connection - ph.load - asum * d.self->evse_power + ph.pv;
+      const double head_room = d.grid_connection - ph.load - asum * d.evse_power + ph.pv;
       const double over = fabs(head_room < 0.0 ? head_room : 0.0);
       if (over > 0.0) {
-        const double pen = overloading_penalty(over / d.self->grid_connection + 1.0, d.self->penalty_overload);
+        const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
         rew += pen;
         penalty_record += pen;
       }

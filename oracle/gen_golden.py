@@ -48,6 +48,9 @@ CONFIGS = {
     "ut3_both_norm_rainflow": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
                                     normalize_in_env=True, calculate_degradation=True, deg_emp=False,
                                     episode_length=48), 3, 2, 2, "wide"),
+    # the headline shape itself: 50 EVs per env (the reference needs ~1.6 s per step here, so one env, one 48 h episode)
+    "ct50_both_rainflow": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                calculate_degradation=True, deg_emp=False, episode_length=48), 50, 1, 1, "wide"),
     # remaining observer variants
     "lmd2_building_norm_noaux": (dict(use_case="lmd", building_name="load_lmd.csv", include_building=True,
                                       include_pv=False, normalize_in_env=True, aux=False,
