@@ -30,7 +30,10 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef FLEET_KBLOCK
+#define FLEET_KBLOCK 256
+#endif
+constexpr int kBlock = FLEET_KBLOCK;  // threads per workgroup
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront helpers
@@ -138,7 +141,9 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
     a[3 * N + c] = ar.hn;
     a[4 * N + c] = ar.lax;
   } else {
+#ifndef FLEET_ABL_NO_RARE
     write_obs_aux_raised_target(*d.self, a, c, tb);
+#endif
   }
 }
 
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers; the few words it needs are re-read
     // from the records this lane has just stored.  One step in 96, and wave-uniform for G == 64.
-#ifdef FLEET_ABL_NO_EVAL
+#if defined(FLEET_ABL_NO_EVAL) || defined(FLEET_ABL_NO_RARE)
     if (false) {
 #else
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
@@ -690,7 +695,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
         d.hot_b[i] = hb;
       }
     }
+#ifdef FLEET_ABL_NO_RARE
+    if (false) {
+#else
     if (is_done) {
+#endif
       n_done += 1;
       if (leader && env_ok) {
         EnvRec* er = d.env + e;

@@ -76,10 +76,22 @@ def synth_schedule(use_case: str, n_evs: int, seed: int = 1234, year: int = 2020
             sa = np.floor(a * sph).astype(np.int64)
             sb = np.maximum(np.ceil(b * sph).astype(np.int64), sa + 1)
             sb = np.minimum(sb, spd - 1)  # always home again before midnight
-            for day in np.nonzero(active)[0]:
-                r0, r1 = day * spd + sa[day], day * spd + sb[day]
-                driving[ev, r0:r1] = True
-                cons[ev, r0:r1] = kwh[day] / (r1 - r0)
+            days_on = np.nonzero(active)[0]
+            r0 = days_on * spd + sa[days_on]
+            r1 = days_on * spd + sb[days_on]
+            # paint the [r0, r1) runs with a difference array (runs of one leg never overlap)
+            per_slot = kwh[days_on] / (r1 - r0)
+            diff = np.zeros(T + 1)
+            np.add.at(diff, r0, per_slot)
+            np.add.at(diff, r1, -per_slot)
+            flag = np.zeros(T + 1, dtype=np.int64)
+            np.add.at(flag, r0, 1)
+            np.add.at(flag, r1, -1)
+            on = np.cumsum(flag[:T]) > 0
+            # exact per-slot value (a running float sum would accumulate rounding): index of the run each slot belongs to
+            run_id = np.cumsum(np.isin(np.arange(T), r0)) - 1
+            cons[ev, on] += per_slot[run_id[on]]
+            driving[ev, on] = True
     power = np.where(driving, 0.0, uc["power"])
     return Schedule(
         date=np.tile(dates, n_evs),
