@@ -43,12 +43,15 @@ FIELDS = {
     "done": (17, np.uint8, False),
     "episodes": (18, np.int32, False),
     "penalty_record": (19, np.float64, False),
+    "log_overload": (20, np.float64, False),
+    "log_soc_missing": (21, np.float64, False),
+    "log_energy": (22, np.float64, True),
 }
 
 _I32_FIELDS = (
     "abi_version", "struct_bytes", "num_envs", "num_cars", "table_rows", "episode_steps", "price_lookahead",
     "bl_pv_lookahead", "steps_per_hour", "hour_phase", "include_building", "include_pv", "aux", "normalize",
-    "is_caretaker", "deg_mode", "picker_mode", "start_lo", "start_hi", "auto_reset", "env_id_offset", "reserved0",
+    "is_caretaker", "deg_mode", "picker_mode", "start_lo", "start_hi", "auto_reset", "env_id_offset", "log_data",
 )
 _F64_FIELDS = (
     "dt", "evse_power", "obc_max_power", "batt_cap_nominal", "init_battery_cap", "grid_connection",

@@ -316,6 +316,10 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &d.hot_a, EN))) return rc;
   if ((rc = dev_alloc(b, &d.hot_b, EN))) return rc;
   if ((rc = dev_alloc(b, &d.sei, EN))) return rc;
+  if (p->log_data) {
+    if ((rc = dev_alloc(b, &d.log_env, (size_t)E * 2))) return rc;
+    if ((rc = dev_alloc(b, &d.log_energy, EN))) return rc;
+  }
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
     d.rf_row_stride = ((4 + d.stack_cap + 15) / 16) * 16;  // RfAcc header + stack, rounded to whole 128-byte lines
@@ -555,9 +559,10 @@ int fleet_get(fleet_handle h, int field, void* out) {
   size_t bytes = 0;
   switch (field) {
     case FLEET_F_SOC: case FLEET_F_SOH: case FLEET_F_SOC_DEG: case FLEET_F_TARGET_SOC: case FLEET_F_FD_CYC:
-    case FLEET_F_FD_CAL: case FLEET_F_SEI_L: bytes = EN * 8; break;
+    case FLEET_F_FD_CAL: case FLEET_F_SEI_L: case FLEET_F_LOG_ENERGY: bytes = EN * 8; break;
     case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: bytes = EN * 4; break;
-    case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD: bytes = E * 8; break;
+    case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD:
+    case FLEET_F_LOG_OVERLOAD: case FLEET_F_LOG_SOC_MISSING: bytes = E * 8; break;
     case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
     case FLEET_F_EPISODES: bytes = E * 4; break;
     case FLEET_F_DONE: bytes = E; break;

@@ -160,6 +160,8 @@ struct FleetDev {
   RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
+  double* log_env;    // [E][2] {overload_amount, cum_soc_missing} of the last step, or nullptr (log_data off)
+  double* log_energy; // [E,N] (dis)charging energy of the last step, or nullptr
   double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfAcc (4 doubles) followed by the reversal stack, EV-major
                       // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators + the
                       // stack entries around the top) instead of one line per field / stack level

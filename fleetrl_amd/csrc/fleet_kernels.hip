@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     const size_t abase = ((size_t)k * d.E + e) * N;
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
 
-    double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0;
+    double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
     for (int c = g; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
@@ -585,6 +585,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
       rew += pos ? ph.k_charge * grid_e : ph.k_discharge * en;   // :154-156 / :204-206
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
+      if (d.log_energy && env_ok) d.log_energy[i] = en;  // DataLogger "Charging energy" input (log_data only)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
           const double pen = soc_violation_penalty(missing);
           rew += pen;
           penrec += pen;  // episode.penalty_record (:549,566,584)
+          miss_sum += missing;  // cum_soc_missing (:544,561,579), only reported through the data log
         } else {
           rew += d.fully_charged_reward;
         }
@@ -655,6 +657,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     asum = group_sum_to_last<G>(asum);
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
 #endif
+    if (d.log_env) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
       penalty_record += penrec;
@@ -665,6 +668,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
         const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
         rew += pen;
         penalty_record += pen;
+      }
+      if (d.log_env && env_ok) {
+        d.log_env[2 * (size_t)e] = over;          // grid = abs(overload_amount) (:660)
+        d.log_env[2 * (size_t)e + 1] = miss_sum;  // soc_v = abs(cum_soc_missing) (:661)
       }
       ep_return += rew;  // :637
       ep_len += 1;
@@ -756,7 +763,7 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
   const size_t E = d.E, EN = (size_t)d.E * d.N;
   const bool per_car = field == FLEET_F_SOC || field == FLEET_F_HOURS_LEFT || field == FLEET_F_SOH || field == FLEET_F_SOC_DEG ||
                        field == FLEET_F_TARGET_SOC || field == FLEET_F_RF_LEN || field == FLEET_F_FD_CYC ||
-                       field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
+                       field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L || field == FLEET_F_LOG_ENERGY;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
     case FLEET_F_SOC: ((double*)out)[i] = d.hot_a[i].soc; break;
@@ -781,6 +788,9 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)d.env[i].done; break;
     case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].h.episodes; break;
     case FLEET_F_PENALTY_RECORD: ((double*)out)[i] = d.env[i].penalty_record; break;
+    case FLEET_F_LOG_OVERLOAD: ((double*)out)[i] = d.log_env ? d.log_env[2 * i] : 0.0; break;
+    case FLEET_F_LOG_SOC_MISSING: ((double*)out)[i] = d.log_env ? d.log_env[2 * i + 1] : 0.0; break;
+    case FLEET_F_LOG_ENERGY: ((double*)out)[i] = d.log_energy ? d.log_energy[i] : 0.0; break;
     default: break;
   }
 }

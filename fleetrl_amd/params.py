@@ -158,6 +158,7 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     p.start_lo, p.start_hi = lo, hi
     p.auto_reset = int(auto_reset)
     p.env_id_offset = int(env_id_offset)
+    p.log_data = int(bool(rc.raw.get("log_data", False)))
     s = rc.seed if seed is None else seed
     p.seed = int(s) if s is not None else 0
     p.dt = rc.dt

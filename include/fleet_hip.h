@@ -89,7 +89,9 @@ typedef struct FleetParams {
   int32_t auto_reset;       /* 1: VecEnv semantics (done envs are reset inside the step, terminal obs reported)
                                0: gymnasium.Env semantics (obs of a done env is its terminal obs)           */
   int32_t env_id_offset;    /* global index of env 0 of this handle (multi-GPU sharding keeps RNG streams env-stable) */
-  int32_t reserved0;
+  int32_t log_data;         /* 1: keep the per-step quantities of the reference's DataLogger (utils/data_logger/data_logger.py)
+                               that are not step outputs -- grid overload, SOC missing at departure, per-EV energy -- for
+                               FLEET_F_LOG_*; 0: skip them */
   uint64_t seed;            /* Philox key for the random/eval picker */
 
   double dt;                /* hours per step (time_config.py:24) */
@@ -170,6 +172,9 @@ typedef struct FleetEnvBatch* fleet_handle;
 #define FLEET_F_DONE 17          /* u8  [E]   episode.done */
 #define FLEET_F_EPISODES 18      /* i32 [E]   finished-episode counter */
 #define FLEET_F_PENALTY_RECORD 19 /* f64 [E]  episode.penalty_record */
+#define FLEET_F_LOG_OVERLOAD 20   /* f64 [E]   last step's overload_amount [kW] (fleet_environment.py:493,660); needs log_data */
+#define FLEET_F_LOG_SOC_MISSING 21 /* f64 [E]  last step's cum_soc_missing (:544,561,579,661); needs log_data */
+#define FLEET_F_LOG_ENERGY 22     /* f64 [E,N] last step's (dis)charging energy per EV [kWh] (ev_charger.py:114,174); needs log_data */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */

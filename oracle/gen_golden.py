@@ -63,6 +63,12 @@ CONFIGS = {
                                    custom_ev_charger_power_in_kw=22, custom_ev_battery_size_in_kwh=40,
                                    custom_grid_connection_in_kw=200, init_battery_cap=40, obc_max_power=11,
                                    max_batt_cap_in_all_use_cases=60), 3, 2, 2, "full"),
+    # same, with the reference's DataLogger switched on: pins `get_log()` (utils/data_logger/data_logger.py:21-68)
+    "custom3_both_overload_log": (dict(use_case="custom", building_name="load_lmd.csv", include_building=True,
+                                       include_pv=True, calculate_degradation=True, deg_emp=False, episode_length=24,
+                                       custom_ev_charger_power_in_kw=22, custom_ev_battery_size_in_kwh=40,
+                                       custom_grid_connection_in_kw=120, init_battery_cap=40, obc_max_power=22,
+                                       max_batt_cap_in_all_use_cases=60, log_data=True), 3, 2, 2, "full"),
 }
 
 
@@ -88,7 +94,7 @@ def run_config(name: str):
         dp, sched = stacked_inputs_dir(sched_uc, n_evs)
         ov.update(data_path=dp, schedule_name=sched)
     ov.setdefault("target_soc", 0.85)
-    rng = np.random.default_rng(sum(map(ord, name)))
+    rng = np.random.default_rng(sum(map(ord, name.replace("_log", ""))))
     ep_steps = ov["episode_length"] * 4
     total = ep_steps * episodes
     rec = None
@@ -173,6 +179,28 @@ def run_config(name: str):
                 rec["fd_cyc"][e, ep] = sd.fd_cyc
                 rec["fd_cal"][e, ep] = sd.fd_cal
                 rec["sei_l"][e, ep] = sd.l
+        if ov.get("log_data"):
+            lg = env.data_logger.log.reset_index(drop=True)
+            rows = len(lg)
+            if "log_reward" not in rec:
+                rec.update(log_reward=np.zeros((E, rows)), log_cashflow=np.zeros((E, rows)), log_penalty=np.zeros((E, rows)),
+                           log_grid=np.zeros((E, rows)), log_socv=np.zeros((E, rows)), log_episode=np.zeros((E, rows), np.int32),
+                           log_time=np.zeros((E, rows), np.int64), log_deg=np.zeros((E, rows, N)),
+                           log_charge=np.zeros((E, rows, N)), log_soh=np.zeros((E, rows, N)),
+                           log_obs=np.zeros((E, rows, rec["obs"].shape[2]), np.float32), log_action=np.zeros((E, rows, N)))
+            rec["log_reward"][e] = lg["Reward"].astype(float).values
+            rec["log_cashflow"][e] = lg["Cashflow"].astype(float).values
+            rec["log_penalty"][e] = lg["Penalties"].astype(float).values
+            rec["log_grid"][e] = lg["Grid overloading"].astype(float).values
+            rec["log_socv"][e] = lg["SOC violation"].astype(float).values
+            rec["log_episode"][e] = lg["Episode"].astype(int).values
+            rec["log_time"][e] = lg["Time"].values.astype("datetime64[s]").astype(np.int64)
+            for k in range(rows):
+                rec["log_deg"][e, k] = np.broadcast_to(np.asarray(lg["Degradation"].iloc[k], dtype=np.float64), (N,))
+                rec["log_charge"][e, k] = np.asarray(lg["Charging energy"].iloc[k], dtype=np.float64)
+                rec["log_soh"][e, k] = np.asarray(lg["SOH"].iloc[k], dtype=np.float64)
+                rec["log_obs"][e, k] = np.asarray(lg["Observation"].iloc[k], dtype=np.float32)
+                rec["log_action"][e, k] = np.asarray(lg["Action"].iloc[k], dtype=np.float64)
         print(f"  {name}: env {e + 1}/{E} done ({time.time() - t0:.0f}s)", flush=True)
 
     # ---- tables: the reference's db columns for the rows the episodes touch --------------------------------

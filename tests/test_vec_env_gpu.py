@@ -113,3 +113,38 @@ def test_gymnasium_vector_signature_and_torch_path():
     assert term.all() and infos["_final_observation"].all() and infos["final_observation"][0].shape == (v1.core.obs_dim,)
     v1.close()
     v2.close()
+
+
+def test_data_log_matches_the_reference_logger():
+    """`get_log()` after two episodes against the DataLogger DataFrame of the reference (log_data=True), column by
+    column, including the non-obvious ones: Penalties = reward - cashflow*price_multiplier (quirk Q13), Charging energy
+    with its cross-car carry-over (quirk Q8), Degradation only on the 14:45 row, no row for the final step of an episode."""
+    from fleetrl_amd import FleetVecEnv
+
+    g = load_trace("custom3_both_overload_log")
+    venv = FleetVecEnv(g.cfg, g.E, tables=g.tables, start_rows=g.starts, extrema=g.extrema, start_range=(0, 0))
+    venv.reset()
+    for k in range(g.total):
+        venv.step(g.actions[:, k])
+    logs = venv.env_method("get_log")
+    for e in range(g.E):
+        lg = logs[e].reset_index(drop=True)
+        rows = g.log_reward.shape[1]
+        # the reference never logs the reset that follows the last episode; our vec env has auto-reset into a third one
+        assert len(lg) == rows + 1
+        lg = lg.iloc[:rows]
+        np.testing.assert_array_equal(lg["Episode"].values.astype(int), g.log_episode[e])
+        np.testing.assert_array_equal(lg["Time"].values.astype("datetime64[s]").astype(np.int64), g.log_time[e])
+        np.testing.assert_allclose(lg["Reward"].values.astype(float), g.log_reward[e], rtol=1e-6, atol=1e-6)  # float32 rewards of the VecEnv
+        np.testing.assert_allclose(lg["Cashflow"].values.astype(float), g.log_cashflow[e], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(lg["Penalties"].values.astype(float), g.log_penalty[e], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lg["Grid overloading"].values.astype(float), g.log_grid[e], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(lg["SOC violation"].values.astype(float), g.log_socv[e], rtol=1e-9, atol=1e-12)
+        for k in range(rows):
+            np.testing.assert_allclose(np.broadcast_to(lg["Degradation"].iloc[k], (g.N,)), g.log_deg[e, k], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(lg["Charging energy"].iloc[k], g.log_charge[e, k], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(lg["SOH"].iloc[k], g.log_soh[e, k], rtol=1e-9)
+            np.testing.assert_allclose(lg["Observation"].iloc[k], g.log_obs[e, k], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(np.asarray(lg["Action"].iloc[k], dtype=np.float64), g.log_action[e, k])
+    assert (g.log_grid > 0).any() and (g.log_socv > 0).any() and (np.abs(g.log_deg) > 0).any()
+    venv.close()
