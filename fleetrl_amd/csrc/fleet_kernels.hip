@@ -28,6 +28,25 @@
 // (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
 #include "fleet_device.h"
 
+#ifdef FLEET_STAMPS
+// Diagnostic build only (tools/stamps.sh): s_memtime stamps of wave 0 of every workgroup at fixed points of the step,
+// written to a buffer nothing else reads.  Never compiled into the product library.
+__device__ unsigned long long fleet_stamp_buf[4096 * 16];
+#define FLEET_STAMP(k)                                                                                   \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    unsigned long long _t;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) fleet_stamp_buf[blockIdx.x * 16 + (k)] = _t;             \
+  } while (0)
+extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet_stamp_buf), sizeof(fleet_stamp_buf));
+}
+#else
+#define FLEET_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 #ifndef FLEET_KBLOCK
@@ -148,18 +167,30 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
 }
 
 // env-level blocks: a pure function of the table row, pre-assembled (and pre-normalised) on the host.  Lane j copies
-// tail float j to its slot (block A right after the 2N state slots, block B after the 5N auxiliary slots); for the
-// usual sizes (<= G floats) this is one predicated load/store per lane, no loop.
+// tail float j to its slot (block A right after the 2N state slots, block B after the 5N auxiliary slots).  The load
+// is issued early (with the other time-row loads) and the store late: `tail_load` / `tail_store`; for the usual
+// sizes (<= G floats) that is one predicated load and one store per lane, no loop.
 template <int G>
-__device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restrict__ row, int t, int g) {
+__device__ __forceinline__ float tail_load(const FleetDev& d, int t, int g) {
+  const int total = d.tail_a_len + d.tail_b_len;
+  return (g < total) ? d.tab_tail[(size_t)t * d.tail_stride + g] : 0.0f;
+}
+
+template <int G>
+__device__ __forceinline__ void tail_store(const FleetDev& d, float* __restrict__ row, int t, int g, float first) {
   const float* __restrict__ src = d.tab_tail + (size_t)t * d.tail_stride;
   const int na = d.tail_a_len, total = d.tail_a_len + d.tail_b_len;
   const unsigned base_a = 2u * (unsigned)d.N, base_b = 7u * (unsigned)d.N;  // block B: 2N + na + 5N + (j - na) = 7N + j
   int j = g;
-  if (j < total) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
+  if (j < total) row[(j < na ? base_a : base_b) + (unsigned)j] = first;
   if (total > G) {
     for (j += G; j < total; j += G) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
   }
+}
+
+template <int G>
+__device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restrict__ row, int t, int g) {
+  tail_store<G>(d, row, t, g, tail_load<G>(d, t, g));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -461,6 +492,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
 #ifdef FLEET_ABL_EMPTY
   if (d.E > 0) return;
 #endif
+  FLEET_STAMP(0);
   const int N = d.N;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -503,6 +535,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     float* const step_row = resets ? term_row : obs_row;
     const bool write_step_obs = env_ok && (step_row != nullptr);
 
+    FLEET_STAMP(1);
     // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
     // The 64-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
     // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
@@ -512,6 +545,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     const size_t abase = ((size_t)k * d.E + e) * N;
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
+
+    const float tail_first = write_step_obs ? tail_load<G>(d, t1, g) : 0.0f;  // consumed after the lane loop
 
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
     for (int c = g; c < N; c += G) {
@@ -561,6 +596,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       const double tgt = t090 ? 0.9 : d.target_soc;
       const bool present = (th == 1u);
 
+      FLEET_STAMP(2);
       // ---- EvCharger.charge (ev_charger.py:89-222) -----------------------------------------------------------------
       // Both action signs in ONE straight-line flow: every quantity of both branches is computed unconditionally and
       // merged with selects / min / max, so a wavefront whose lanes hold both signs (the normal case) does not walk two
@@ -610,11 +646,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       const double old_deg = ha.soc_deg;
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
 
+      FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
 #ifndef FLEET_ABL_NO_OBS
       if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
 #endif
 
+      FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       int tail = HOT_TAIL(hb.bits), head = HOT_HEAD(hb.bits), sgn = HOT_SGN(hb.bits);
       double soh = hb.soh;
@@ -632,6 +670,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
       if (DEG == FLEET_DEG_RAINFLOW) asm volatile("" ::"v"(rf_touch));  // keep the touch load alive
+      FLEET_STAMP(5);
       if (env_ok) {  // whole 16-byte records, always: dense full-line stores
         HotA na;
         na.soc = soc;
@@ -646,10 +685,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
       }
     }
 #ifndef FLEET_ABL_NO_OBS
-    if (write_step_obs) write_obs_tail<G>(d, step_row, t1, g);
+    if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
 #endif
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
+    FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
 #ifndef FLEET_ABL_NO_REDUCE
     cash = group_sum_to_last<G>(cash);
@@ -684,6 +724,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
         }
       }
     }
+    FLEET_STAMP(7);
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers; the few words it needs are re-read
@@ -742,6 +783,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     }
   }
   if (err && env_ok) atomicOr(&d.env[e].err, err);
+  FLEET_STAMP(8);
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)
