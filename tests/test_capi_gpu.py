@@ -1,0 +1,131 @@
+"""C-ABI behaviours on the GPU beyond plain stepping: K-steps-per-launch equals K launches, tape replay through a
+captured hipGraph, masked reset, external stream adoption, error reporting.  Needs an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden_util import load_trace, params_for
+from fleetrl_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(name="ct5_both_rainflow", E=37, seed=5, **kw):
+    from fleetrl_amd.batch import FleetBatch
+
+    g = load_trace(name)
+    p = params_for(g, num_envs=E, **kw)
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, g.tables.T - g.ep_steps - 60, size=(4, E)).astype(np.int32)
+    b = FleetBatch(p, g.tables, g.time_feat)
+    b.set_start_schedule(starts)
+    return g, b, rng
+
+
+def test_step_many_and_graph_tape_equal_single_steps():
+    import torch
+
+    dev = torch.device("cuda", 0)
+    K = 230
+    g, a, rng = _mk()
+    _, b, _ = _mk()
+    _, c, _ = _mk()
+    acts = rng.uniform(-1, 1, size=(K, a.E, g.N)).astype(np.float32)
+    a.reset(); b.reset(); c.reset()
+    want_r = np.zeros(a.E); want_d = np.zeros(a.E, dtype=np.int32)
+    for k in range(K):
+        o, r, d, _t = a.step(acts[k])
+        want_r += r; want_d += d
+    tape = torch.from_numpy(acts).to(dev)
+    obs = torch.empty((a.E, a.obs_dim), device=dev); rs = torch.empty(a.E, device=dev, dtype=torch.float64)
+    dc = torch.empty(a.E, device=dev, dtype=torch.int32); dn = torch.empty(a.E, device=dev, dtype=torch.uint8)
+    b.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rs.data_ptr(), dc.data_ptr())
+    b.synchronize()
+    np.testing.assert_array_equal(dc.cpu().numpy(), want_d)
+    np.testing.assert_allclose(rs.cpu().numpy(), want_r, rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(obs.cpu().numpy(), o)
+    for f in ("soc", "soh", "hours_left", "time_idx", "rf_len", "fd_cyc", "episodes", "ep_return"):
+        np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
+    # the same tape, one launch per step, replayed through a captured hipGraph (tape_len | K not required)
+    c.run_tape_dev(K, tape.data_ptr(), 23, obs.data_ptr(), rs.data_ptr(), dn.data_ptr(), use_graph=True)
+    c.synchronize()
+    _, d2, _ = _mk()
+    d2.reset()
+    for k in range(K):
+        o2, r2, dd2, _t = d2.step(acts[k % 23])
+    np.testing.assert_array_equal(obs.cpu().numpy(), o2)
+    np.testing.assert_array_equal(rs.cpu().numpy(), r2)  # run_tape writes the LAST step's reward/done
+    np.testing.assert_array_equal(dn.cpu().numpy(), dd2)
+    for f in ("soc", "soh", "time_idx", "episodes"):
+        np.testing.assert_array_equal(c.get(f), d2.get(f), err_msg=f)
+    per = c.time_steps_dev(5, tape.data_ptr(), 23, obs.data_ptr(), rs.data_ptr(), dn.data_ptr())
+    assert per.shape == (5,) and (per > 0).all() and (per < 5.0).all()
+    for x in (a, b, c, d2):
+        x.check_errors(); x.close()
+
+
+def test_masked_reset_and_abandoned_episode_counting():
+    g, b, rng = _mk(E=9)
+    obs0 = b.reset()
+    for _ in range(5):
+        b.step(rng.uniform(-1, 1, size=(b.E, g.N)).astype(np.float32))
+    t_before, ep_before = b.get("time_idx"), b.get("episodes")
+    mask = np.zeros(b.E, dtype=np.uint8); mask[[1, 4]] = 1
+    keep = np.full((b.E, b.obs_dim), 7.0, dtype=np.float32)
+    out = b.reset(mask=mask, out=keep.copy())
+    assert np.all(out[[0, 2, 3]] == 7.0) and not np.any(out[[1, 4]] == 7.0)   # unmasked rows untouched
+    t_after, ep_after = b.get("time_idx"), b.get("episodes")
+    assert np.array_equal(t_after[[0, 2, 3, 5]], t_before[[0, 2, 3, 5]])
+    assert np.array_equal(ep_after[[1, 4]], ep_before[[1, 4]] + 1) and np.array_equal(ep_after[[0, 2]], ep_before[[0, 2]])
+    assert np.array_equal(b.get("ep_len")[[1, 4]], [0, 0]) and b.get("ep_len")[0] == 5
+    b.close()
+
+
+def test_adopts_an_external_stream():
+    import torch
+
+    g, b, rng = _mk(E=5)
+    s = torch.cuda.Stream()
+    b.set_stream(s.cuda_stream)
+    dev = torch.device("cuda", 0)
+    obs = torch.empty((b.E, b.obs_dim), device=dev); rew = torch.empty(b.E, device=dev, dtype=torch.float64)
+    done = torch.empty(b.E, device=dev, dtype=torch.uint8)
+    with torch.cuda.stream(s):
+        b.reset_dev(obs.data_ptr())
+        a = torch.rand((b.E, g.N), device=dev) * 2 - 1
+        b.step_dev(a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    s.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    b.close()
+
+
+def test_error_reporting():
+    from fleetrl_amd.batch import FleetBatch, FleetHipError
+
+    g = load_trace("ct2_pv_nodeg")
+    p = params_for(g)
+    p.abi_version = 99
+    with pytest.raises(FleetHipError) as ei:
+        FleetBatch(p, g.tables, g.time_feat)
+    assert ei.value.status == _capi.ERR_INVALID and "abi" in str(ei.value)
+    p = params_for(g)
+    p.deg_mode, p.init_soh = _capi.DEG_RAINFLOW, 0.95
+    with pytest.raises(FleetHipError):
+        FleetBatch(p, g.tables, g.time_feat)
+    p = params_for(g)
+    b = FleetBatch(p, g.tables, g.time_feat)
+    with pytest.raises(FleetHipError):
+        b.set_start_schedule(np.full((1, b.E), g.tables.T + 5, dtype=np.int32))
+    with pytest.raises(ValueError):
+        b.step(np.zeros((b.E + 1, g.N), dtype=np.float32))
+    with pytest.raises(KeyError):
+        b.get("no_such_field")
+    # an episode that would run past the table raises the device error word instead of reading out of bounds
+    b.set_start_schedule(np.full((1, b.E), g.tables.T - 10, dtype=np.int32))
+    b.reset()
+    with pytest.raises(FleetHipError) as ei:
+        b.check_errors()
+    assert ei.value.status == _capi.ERR_STATE
+    assert (b.get("error_bits") & _capi.DEVERR_TABLE_END).all()
+    b.close()
