@@ -32,6 +32,7 @@ class FleetBatch:
         self.device = int(device)
         self.E, self.N = int(params.num_envs), int(params.num_cars)
         self.obs_dim = int(self.lib.fleet_obs_dim(C.byref(params)))
+        self._term = None
 
     # ------------------------------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -83,10 +84,13 @@ class FleetBatch:
         return a, dt
 
     def step(self, actions):
-        """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim])"""
+        """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim]); `terminal_obs` is a buffer
+        reused between calls whose rows are valid only where `done` is set."""
         a, dt = self._act(actions, (self.E, self.N))
         obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
-        term = np.zeros((self.E, self.obs_dim), dtype=np.float32)
+        if self._term is None:  # reused across steps: only the rows of envs that just finished are meaningful
+            self._term = np.zeros((self.E, self.obs_dim), dtype=np.float32)
+        term = self._term
         rew = np.empty(self.E)
         done = np.empty(self.E, dtype=np.uint8)
         self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,

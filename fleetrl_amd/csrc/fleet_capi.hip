@@ -547,8 +547,17 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
   HIP_TRY(h, hipMemcpyAsync(obs, h->st_obs, OD, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(reward, h->st_reward, h->d.E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(done, h->st_done, h->d.E, hipMemcpyDeviceToHost, h->stream));
-  if (terminal_obs) HIP_TRY(h, hipMemcpyAsync(terminal_obs, h->st_term, OD, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (terminal_obs) {
+    // terminal observations only exist for envs that finished in this step: move them (a full-size transfer
+    // otherwise) only when there is one; rows of envs that did not finish are left untouched
+    bool any = false;
+    for (int e = 0; e < h->d.E && !any; ++e) any = done[e] != 0;
+    if (any) {
+      HIP_TRY(h, hipMemcpyAsync(terminal_obs, h->st_term, OD, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
   return FLEET_OK;
 }
 

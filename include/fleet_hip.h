@@ -206,6 +206,7 @@ int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, doub
 
 /* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);
+/* terminal_obs (or NULL): rows of envs that finished in this step are written; all other rows are left untouched */
 int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
                     uint8_t* done, float* terminal_obs);
 
