@@ -539,7 +539,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
     // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
     // The 64-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
     // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
-    const PhysRow ph = d.tab_phys[t + vzero];
+    // (not in rainflow mode, where vector registers are the scarcer resource)
+    const PhysRow ph = d.tab_phys[t + (DEG == FLEET_DEG_RAINFLOW ? 0 : vzero)];
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
