@@ -49,6 +49,9 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
+#ifndef FLEET_MULTI_WAVES
+#define FLEET_MULTI_WAVES 2  // waves per SIMD the multi-step kernel is compiled for (register budget 512 / this)
+#endif
 #ifndef FLEET_KBLOCK
 #define FLEET_KBLOCK 256
 #endif
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI>
-__global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
+__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
@@ -549,8 +552,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? 2 : 4) void fleet_step_kernel(Fleet
 
     const float tail_first = write_step_obs ? tail_load<G>(d, t1, g) : 0.0f;  // consumed after the lane loop
 
+    // Multi-step launches: an opaque per-iteration zero keeps the compiler from hoisting every lane address of the step
+    // body out of the K loop (60 extra live vector registers = half the resident wavefronts); recomputing them each
+    // step costs a handful of integer instructions.
+    int kz = 0;
+    if (MULTI) asm volatile("" : "+v"(kz));
+
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
-    for (int c = g; c < N; c += G) {
+    for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
       const HotA ha = d.hot_a[i];

@@ -98,3 +98,41 @@ def test_observer_variants(aux, building, pv, norm):
 def test_headline_shape_slice():
     """50 EVs per env (one wavefront per env), caretaker fleet, load+pv, rainflow: the bench workload at 96 envs."""
     _compare("ct", 50, 96, "rainflow", False, steps=220)
+
+
+def test_long_soak_many_episodes():
+    """1000 steps (ten 24 h episodes per env) at the headline geometry: accumulated degradation bookkeeping
+    (rainflow_length / fd_cyc / l carried across episodes, quirk Q6) must stay in lock-step with the oracle."""
+    _compare("ct", 50, 24, "rainflow", False, steps=1000, seed=3)
+
+
+def test_float64_actions_and_static_eval_pickers():
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+
+    tb = _tables("lmd", 7)
+    for picker in ("static", "eval"):
+        cfg = _cfg("lmd", "linear", False)
+        cfg["time_picker"] = picker
+        rc = resolve_config(cfg)
+        p = make_params(rc, tb, 11, seed=9)
+        tf = time_features(tb)
+        hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf)
+        np.testing.assert_array_equal(hip.reset(), cpu.reset())
+        st = hip.get("start_idx")
+        if picker == "static":
+            assert (st == 172).all()  # "01/02/2021 19:00" re-based to the table's year
+        else:
+            assert st.min() >= p.start_lo and st.max() <= p.start_hi and len(set(st.tolist())) > 1
+        rng = np.random.default_rng(2)
+        for s in range(110):
+            a = rng.uniform(-1, 1, size=(11, 7))  # float64, not float32-representable
+            oh, rh, dh, _ = hip.step(a)
+            oc, rcpu, dc, _ = cpu.step(a)
+            np.testing.assert_array_equal(dh, dc)
+            np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(rh, rcpu, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(hip.get("soc"), cpu.get("soc"), rtol=1e-12, atol=1e-15)
+        np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))
+        hip.close()
+        cpu.close()
