@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
 PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
-POLICY_UNCONTROLLED, POLICY_DISTRIBUTED = 2, 3
+POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
 DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END = 1, 2, 4, 8, 16
 
@@ -145,6 +145,7 @@ def load_library():
     lib.fleet_step_dev.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
     lib.fleet_step_many_dev.argtypes = [vp, C.c_int, vp, C.c_int, f32p, f64p, vp]
     lib.fleet_rollout_policy_dev.argtypes = [vp, C.c_int, C.c_int, f32p, f64p, vp]
+    lib.fleet_set_night_policy.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.fleet_reset_host.argtypes = [vp, u8p, f32p]
     lib.fleet_step_host.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
     lib.fleet_get.argtypes = [vp, C.c_int, vp]
@@ -155,8 +156,8 @@ def load_library():
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_synchronize", "fleet_set_start_schedule",
-                 "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_reset_host",
-                 "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start", "fleet_timer_stop",
+                 "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
+                 "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start", "fleet_timer_stop",
                  "fleet_run_tape_dev", "fleet_time_steps_dev"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
@@ -166,7 +167,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_synchronize",
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev",
-    "fleet_reset_host",
+    "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev",
 )

@@ -110,8 +110,12 @@ class FleetBatch:
         self._check(self.lib.fleet_step_many_dev(self.h, int(K), actions_ptr, act_dtype, obs_ptr, reward_sum_ptr, done_count_ptr))
 
     def rollout_policy_dev(self, policy: int, K: int, obs_ptr: int, reward_sum_ptr: int, done_count_ptr: int | None = None):
-        """K steps in one launch with a built-in policy (_capi.POLICY_UNCONTROLLED / POLICY_DISTRIBUTED)."""
+        """K steps in one launch with a built-in policy (_capi.POLICY_UNCONTROLLED / POLICY_DISTRIBUTED / POLICY_NIGHT)."""
         self._check(self.lib.fleet_rollout_policy_dev(self.h, int(policy), int(K), obs_ptr, reward_sum_ptr, done_count_ptr))
+
+    def set_night_policy(self, charging_hour: int, charging_minute: int, max_hours: int):
+        """Parameters of _capi.POLICY_NIGHT (see fleetrl_amd.policies.night_schedule); clears the per-env window state."""
+        self._check(self.lib.fleet_set_night_policy(self.h, int(charging_hour), int(charging_minute), int(max_hours)))
 
     def run_tape_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
                      use_graph: bool = True, act_dtype: int = _capi.ACT_F32):

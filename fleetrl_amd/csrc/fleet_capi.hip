@@ -307,6 +307,18 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
     HIP_TRY(b, hipStreamSynchronize(b->stream));  // host vectors go out of scope here
   }
+  {
+    // night-charging policy (benchmarking/night_charging.py:81-98): clock of every table row + per-env window state
+    std::vector<uint16_t> hm((size_t)T);
+    for (int i = 0; i < T; ++i) hm[i] = (uint16_t)((t->hour[i] << 8) | t->minute[i]);
+    if ((rc = dev_upload(b, &cd.tab_hm, hm.data(), hm.size()))) return rc;
+    std::vector<int32_t> idle((size_t)E, FLEET_NIGHT_IDLE);
+    if ((rc = dev_alloc(b, &cd.night_start, (size_t)E, false))) return rc;
+    HIP_TRY(b, hipMemcpyAsync(cd.night_start, idle.data(), idle.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    cd.night_hour = -1; cd.night_minute = 0; cd.night_limit_s = 0;
+    cd.step_s = (int)std::llround(p->dt * 3600.0);
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+  }
   if ((rc = dev_alloc(b, &b->cold_dev, 1))) return rc;
   HIP_TRY(b, hipMemcpyAsync(b->cold_dev, &cd, sizeof(FleetCold), hipMemcpyHostToDevice, b->stream));
   d.cold = b->cold_dev;
@@ -502,10 +514,33 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
   return FLEET_OK;
 }
 
+int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minute, int max_hours) {
+  if (!h) return FLEET_ERR_INVALID;
+  // charging_hour may be 24 (the reference's own edge when the window would open exactly at midnight: never opens)
+  if (charging_hour < 0 || charging_hour > 24 || charging_minute < 0 || charging_minute > 59 || max_hours < 0 ||
+      max_hours > 24 * 365) {
+    h->error = "fleet_set_night_policy: argument out of range";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->cold_host.night_hour = charging_hour;
+  h->cold_host.night_minute = charging_minute;
+  h->cold_host.night_limit_s = 3600 * max_hours;
+  std::vector<int32_t> idle((size_t)h->d.E, FLEET_NIGHT_IDLE);
+  HIP_TRY(h, hipMemcpy(h->cold_host.night_start, idle.data(), idle.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->cold_dev, &h->cold_host, sizeof(FleetCold), hipMemcpyHostToDevice));
+  return FLEET_OK;
+}
+
 int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count) {
   if (!h || K < 1 || !obs || !reward_sum ||
-      (policy != FLEET_ACT_POLICY_UNCONTROLLED && policy != FLEET_ACT_POLICY_DISTRIBUTED)) {
+      (policy != FLEET_ACT_POLICY_UNCONTROLLED && policy != FLEET_ACT_POLICY_DISTRIBUTED && policy != FLEET_ACT_POLICY_NIGHT)) {
     if (h) h->error = "fleet_rollout_policy_dev: bad argument";
+    return FLEET_ERR_INVALID;
+  }
+  if (policy == FLEET_ACT_POLICY_NIGHT && h->cold_host.night_hour < 0) {
+    h->error = "fleet_rollout_policy_dev: FLEET_ACT_POLICY_NIGHT needs fleet_set_night_policy first";
     return FLEET_ERR_INVALID;
   }
   if (!h->d.auto_reset) {

@@ -132,7 +132,14 @@ struct FleetCold {
   int sched_n;
   int normalize;
   const int32_t* sched;  // [sched_n, E]
+  // FLEET_ACT_POLICY_NIGHT (benchmarking/night_charging.py:50-98)
+  const uint16_t* tab_hm;  // [T] hour << 8 | minute of the table row
+  int32_t* night_start;    // [E] row at which the env's charging window opened, FLEET_NIGHT_IDLE when closed
+  int night_hour, night_minute;  // charging_hour / charging_minute; night_hour < 0: not configured
+  int night_limit_s;       // 3600 * int(max_time_needed)
+  int step_s;              // seconds per table row
 };
+#define FLEET_NIGHT_IDLE INT32_MIN
 
 struct FleetDev {
   // ---- sizes / flags --------------------------------------------------------------------------------

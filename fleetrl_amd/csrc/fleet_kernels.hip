@@ -527,6 +527,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
   const int steps = MULTI ? K : 1;
   const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
+  // night-charging policy: the env's "charging since" row travels in a register over the K steps
+  int night_st = FLEET_NIGHT_IDLE;
+  if (MULTI && act_mode == FLEET_ACT_POLICY_NIGHT) {
+    night_st = d.cold->night_start[e];
+    if (G == 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
+  }
 
   for (int k = 0; k < steps; ++k) {
     const int t = r.t;
@@ -558,6 +564,29 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     int kz = 0;
     if (MULTI) asm volatile("" : "+v"(kz));
 
+    // Which action rule applies to this env in this step (policies only; FLEET_ACT_POLICY_NIGHT resolves to one of
+    // "all zeros" / "all ones" / the distributed rule per step, benchmarking/night_charging.py:81-98)
+    int pol = act_mode;
+    if (MULTI && act_mode == FLEET_ACT_POLICY_NIGHT) {
+      const FleetCold* cd = d.cold;
+      const int hm = cd->tab_hm[t];
+      const int hour = hm >> 8, minute = hm & 255;
+      if (d.is_caretaker && hour >= 11 && hour <= 14) {
+        pol = FLEET_ACT_POLICY_DISTRIBUTED;  // :85-88, `continue`: the window bookkeeping below is skipped
+      } else {
+        bool charging = (night_st != FLEET_NIGHT_IDLE);
+        if ((cd->night_hour <= hour && cd->night_minute <= minute) || charging) {  // :90
+          if (!charging) night_st = t;  // charging_start = copy(time) :91-92
+          charging = true;
+          pol = FLEET_ACT_POLICY_UNCONTROLLED;  // np.ones :94
+        } else {
+          pol = -1;  // np.zeros :96
+        }
+        // :97-98  (time - charging_start).total_seconds() / 3600 > int(max_time_needed); rows are a regular grid
+        if (charging && (t - night_st) * cd->step_s > cd->night_limit_s) night_st = FLEET_NIGHT_IDLE;
+      }
+    }
+
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
@@ -569,8 +598,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
-        if (act_mode == FLEET_ACT_POLICY_UNCONTROLLED) {
+        if (pol == FLEET_ACT_POLICY_UNCONTROLLED) {
           a = 1.0;  // benchmarking/uncontrolled_charging.py:51-54: np.ones(n_evs)
+        } else if (pol < 0) {
+          a = 0.0;
         } else {
           // benchmarking/distributed_charging.py:50-54: clip(get_dist_factor(), 0, 1), get_dist_factor =
           // hours_needed / (hours_left + 0.001) from the TABLE row of the current time (fleet_environment.py:782-799)
@@ -790,6 +821,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     if (MULTI) {
       reward[e] = reward_sum;
       if (done_count) done_count[e] = n_done;
+      if (act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
   }
   if (err && env_ok) atomicOr(&d.env[e].err, err);

@@ -53,6 +53,8 @@ extern "C" {
 /* built-in open-loop policies (fleet_rollout_policy_dev): the action rules of the reference's benchmark harnesses */
 #define FLEET_ACT_POLICY_UNCONTROLLED 2 /* all ones           (benchmarking/uncontrolled_charging.py:51-54) */
 #define FLEET_ACT_POLICY_DISTRIBUTED 3  /* clip(get_dist_factor(), 0, 1) (benchmarking/distributed_charging.py:50-54) */
+#define FLEET_ACT_POLICY_NIGHT 4        /* time-window rule, stateful per env (benchmarking/night_charging.py:81-98);
+                                           configure with fleet_set_night_policy first */
 
 /* device-side error bits (per env, OR-ed into one word; see fleet_get(FLEET_F_ERROR_BITS))               */
 #define FLEET_DEVERR_OBS_FORMAT 1u     /* the reference's `raise TypeError("Observation format not recognized")` :610 */
@@ -203,6 +205,13 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
  * action tape: the reference's `benchmarking/` harnesses without a host round trip per step.  Outputs as
  * fleet_step_many_dev.  auto_reset must be 1. */
 int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count);
+/* Parameters of FLEET_ACT_POLICY_NIGHT, as the reference's harness derives them before its loop
+ * (benchmarking/night_charging.py:50-73): charging starts when `charging_hour <= hour && charging_minute <= minute`
+ * of the env's current row (the reference's own, non-lexicographic test), runs until more than `max_hours`
+ * (= int(max_time_needed)) have passed since it started, and on a caretaker fleet the rows of hours 11..14 use the
+ * distributed rule instead.  Each env keeps its own "charging since" state, which -- like the reference's loop
+ * variable -- survives episode resets; this call clears it.  Not callable while a captured graph is replaying. */
+int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minute, int max_hours);
 
 /* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);

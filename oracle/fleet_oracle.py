@@ -128,3 +128,46 @@ class OracleBatch:
         out = np.zeros((self.E, self.N))
         self.lib.oracle_get_dist_factor(self.h, out.ctypes.data)
         return out
+
+
+class NightChargingRule:
+    """The action rule of the reference's night-charging benchmark loop, one instance per env
+    (benchmarking/night_charging.py:81-98): the `charging` / `charging_start` loop variables live here and, as in the
+    reference, are NOT cleared when the episode resets.  `parameters()` restates :50-73 with pandas objects replaced by
+    the (hour, minute) of the rows where a vehicle leaves home."""
+
+    def __init__(self, charging_hour: int, charging_minute: int, max_time_needed: float, minutes_per_step: int, is_ct: bool):
+        self.charging_hour, self.charging_minute = charging_hour, charging_minute
+        self.max_time_needed, self.minutes, self.is_ct = max_time_needed, minutes_per_step, is_ct
+        self.charging = False
+        self.charging_start = None
+
+    @staticmethod
+    def parameters(leave_hours, leave_minutes, target_soc, cap, eff, evse):
+        import math
+        earliest = min(zip(leave_hours, leave_minutes))  # df_leaving_home['date'].dt.time.min() :54
+        earliest_dep = earliest[0] + earliest[1] / 60  # :56
+        max_time_needed = target_soc * cap / eff / evse  # :63
+        starting_time = 24 + (earliest_dep - max_time_needed)  # :64-65
+        if starting_time > 24:
+            starting_time = 23.99  # :66-67
+        charging_hour = int(math.modf(starting_time)[1])  # :69
+        minutes = np.asarray([0, 15, 30, 45])
+        closest_index = np.abs(minutes - int(math.modf(starting_time)[0] * 60)).argmin()  # :72
+        return charging_hour, int(minutes[closest_index]), max_time_needed
+
+    def action(self, row: int, hour: int, minute: int, n_evs: int, dist_factor: np.ndarray) -> np.ndarray:
+        """Action for the env whose current table row is `row` (clock `hour`:`minute`); updates the loop state."""
+        if 11 <= hour <= 14 and self.is_ct:  # :85-88 (`continue`: no bookkeeping on these rows)
+            return np.clip(np.ones(n_evs) * dist_factor, 0, 1)
+        if (self.charging_hour <= hour and self.charging_minute <= minute) or self.charging:  # :90
+            if not self.charging:
+                self.charging_start = row  # :91-92
+            self.charging = True
+            a = np.ones(n_evs)  # :94
+        else:
+            a = np.zeros(n_evs)  # :96
+        # :97-98 -- timestamps of a regular grid: (time - charging_start) = (row - start_row) * minutes
+        if self.charging and ((row - self.charging_start) * self.minutes * 60) / 3600 > int(self.max_time_needed):
+            self.charging = False
+        return a
