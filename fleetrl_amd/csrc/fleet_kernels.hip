@@ -145,6 +145,37 @@ __device__ __forceinline__ void write_obs_aux_raised_target(const FleetDev& d, f
   }
 }
 
+// Streaming (non-temporal) stores / loads for data the launch touches exactly once: they do not linger dirty in the
+// write-back L2 until the end-of-kernel release has to flush them.
+typedef double fleet_v2d __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void st_rec16(T* p, const T& v) {
+  static_assert(sizeof(T) == 16, "16-byte record");
+#ifdef FLEET_NT_STATE
+  __builtin_nontemporal_store(*reinterpret_cast<const fleet_v2d*>(&v), reinterpret_cast<fleet_v2d*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ TabX ld_tabx(const TabX* p) {
+#ifdef FLEET_NT_TAB
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const v4d raw = __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p));
+  TabX out;
+  __builtin_memcpy(&out, &raw, sizeof(TabX));
+  return out;
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_obs(float* p, float v) {
+#ifdef FLEET_NT_OBS
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the
 // step advanced to (quirk Q10) -- pre-assembled on the host for the configured target SOC (AuxRec `ar`, loaded
 // by the caller together with the table record), recomputed here only for an EV whose target has been raised to
@@ -152,16 +183,16 @@ __device__ __forceinline__ void write_obs_aux_raised_target(const FleetDev& d, f
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
                                              const TabRec& tb, const AuxRec& ar) {
   const int N = d.N;
-  row[c] = (float)soc;
-  row[N + c] = d.normalize ? (float)((double)hl / d.self->max_time_left) : hl;
+  st_obs(row + c, (float)soc);
+  st_obs(row + N + c, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
-  a[c] = (float)tb.there;
+  st_obs(a + c, (float)tb.there);
   if (!t090) {
-    a[N + c] = ar.tgt_th;
-    a[2 * N + c] = ar.cl;
-    a[3 * N + c] = ar.hn;
-    a[4 * N + c] = ar.lax;
+    st_obs(a + N + c, ar.tgt_th);
+    st_obs(a + 2 * N + c, ar.cl);
+    st_obs(a + 3 * N + c, ar.hn);
+    st_obs(a + 4 * N + c, ar.lax);
   } else {
 #ifndef FLEET_ABL_NO_RARE
     write_obs_aux_raised_target(*d.self, a, c, tb);
@@ -185,7 +216,7 @@ __device__ __forceinline__ void tail_store(const FleetDev& d, float* __restrict_
   const int na = d.tail_a_len, total = d.tail_a_len + d.tail_b_len;
   const unsigned base_a = 2u * (unsigned)d.N, base_b = 7u * (unsigned)d.N;  // block B: 2N + na + 5N + (j - na) = 7N + j
   int j = g;
-  if (j < total) row[(j < na ? base_a : base_b) + (unsigned)j] = first;
+  if (j < total) st_obs(row + ((j < na ? base_a : base_b) + (unsigned)j), first);
   if (total > G) {
     for (j += G; j < total; j += G) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
   }
@@ -487,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG, bool MULTI>
+template <int G, int DEG, bool MULTI, bool WIDE>
 __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
@@ -504,6 +535,24 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
   const bool env_ok = e_raw < d.E;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
   const int e = env_ok ? e_raw : d.E - 1;
   const size_t EN = (size_t)d.E * N;
+
+  // One launch = one step and one EV per lane (N <= G): the lane's state records and its action do not depend on the
+  // env's time row, so they are requested before the env record is even read -- their latency then overlaps the
+  // env record -> time row -> table record chain instead of following it.
+  constexpr bool kEarly = !MULTI && !WIDE;
+  HotA ha_pre = {0.0, 0.0};
+  HotB hb_pre = {0.0, 0.0f, 0u};
+  RfTop top_pre = {0.0, 0.0};
+  float a32_pre = 0.0f;
+  double a64_pre = 0.0;
+  if (kEarly && g < N) {
+    const size_t i0 = (size_t)e * N + g;
+    ha_pre = d.hot_a[i0];
+    hb_pre = d.hot_b[i0];
+    if (DEG == FLEET_DEG_RAINFLOW) top_pre = d.rf_top[i0];
+    if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)actions)[i0];
+    else a32_pre = ((const float*)actions)[i0];
+  }
 
   EnvHead r = d.env[e].h;
   if (G == 64) {
@@ -591,10 +640,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
-      const HotA ha = d.hot_a[i];
-      const HotB hb = d.hot_b[i];
+      const HotA ha = kEarly ? ha_pre : d.hot_a[i];
+      const HotB hb = kEarly ? hb_pre : d.hot_b[i];
       RfTop top = {0.0, 0.0};
-      if (DEG == FLEET_DEG_RAINFLOW) top = d.rf_top[i];
+      if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -613,10 +662,15 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
           const double f = hn0 / ((double)tb0.tl + 0.001);
           a = f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
         }
+      } else if (kEarly) {
+        // the widening must stay here: hoisted into the early-load block it would wait for every outstanding load
+        float a32 = a32_pre;
+        asm volatile("" : "+v"(a32));
+        a = (act_mode == FLEET_ACT_F64) ? a64_pre : (double)a32;
       } else {
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
-      const TabX tx1 = tab_t1[c];
+      const TabX tx1 = ld_tabx(tab_t1 + c);
       const TabRec tb1 = tx1.tb;
       const AuxRec ar = tx1.ar;
       // Rainflow: a present EV with a non-zero action will most likely change its SOC slope bookkeeping this step;
@@ -720,10 +774,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
         nb.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
         nb.hl = hl;
         nb.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
-        d.hot_a[i] = na;
-        d.hot_b[i] = nb;
-        if (DEG == FLEET_DEG_RAINFLOW) d.rf_top[i] = top;
+        st_rec16(d.hot_a + i, na);
+        st_rec16(d.hot_b + i, nb);
+        if (DEG == FLEET_DEG_RAINFLOW) st_rec16(d.rf_top + i, top);
       }
+      if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
 #ifndef FLEET_ABL_NO_OBS
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -782,6 +837,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
         const RfTop top = d.rf_top[i];
         hb.soh = hb.soh - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err);
         d.hot_b[i] = hb;
+        if (!WIDE) break;
       }
     }
 #ifdef FLEET_ABL_NO_RARE
@@ -891,12 +947,22 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-  if (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED)
-    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false>), grid, block, 0, s, d, actions, f64, 1, obs, reward, done,
-                       terminal_obs, done_count);
-  else
-    hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true>), grid, block, 0, s, d, actions, f64, K, obs, reward, done,
-                       terminal_obs, done_count);
+  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED);
+  if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
+    if (single)
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, d, actions, f64, 1, obs, reward,
+                         done, terminal_obs, done_count);
+    else
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, d, actions, f64, K, obs, reward,
+                         done, terminal_obs, done_count);
+  } else {
+    if (single)
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, d, actions, f64, 1, obs, reward, done,
+                         terminal_obs, done_count);
+    else
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false>), grid, block, 0, s, d, actions, f64, K, obs, reward, done,
+                         terminal_obs, done_count);
+  }
   return hipGetLastError();
 }
 
