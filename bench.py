@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tape-len", type=int, default=64)
+    ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
     ap.add_argument("--deg", default="rainflow", choices=["none", "linear", "rainflow"],
                     help="degradation model (default rainflow = the BASELINE workload; others are diagnostics)")
     args = ap.parse_args()
@@ -160,8 +161,17 @@ def main():
         batch.run_tape_dev(k, tape.data_ptr(), L, obs.data_ptr(), reward.data_ptr(), done.data_ptr(), use_graph=use_graph)
 
     batch.reset_dev(obs.data_ptr())
+    # clock ramp: replay the same step (untimed) for a fixed wall time before the W warmup steps, so that a short
+    # --steps/--warmup run measures the same steady state as a long one
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        run(256)
+        batch.synchronize()
     run(args.warmup)
     batch.synchronize()
+    ret = torch.zeros(E, device=dev, dtype=torch.float64)
+    ln = torch.zeros(E, device=dev, dtype=torch.int32)
+    gather_episode_stats(ret, ln)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
 
     def barrier():
         torch.cuda.synchronize()
@@ -175,8 +185,9 @@ def main():
     run(args.steps)
     ev_ms = batch.timer_stop()  # HIP events on the stream the kernels run on
     # logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1)
-    ret = torch.from_numpy(batch.get("last_ep_return")).to(dev)
-    ln = torch.from_numpy(batch.get("last_ep_len")).to(dev)
+    batch.get_dev("last_ep_return", ret.data_ptr())  # device-side unpack, no host round trip
+    batch.get_dev("last_ep_len", ln.data_ptr())
+    batch.synchronize()
     r_all, n_all = gather_episode_stats(ret, ln)
     barrier()
     wall = time.perf_counter() - t0
@@ -225,7 +236,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{E} envs x {N} EVs per GPU, {args.use_case} fleet, load+pv obs, rainflow/SEI degradation, "
                                    f"48 h episodes, random start rows, auto-reset (BASELINE.json configs[2])",
-                       "envs_per_gpu": E, "evs_per_env": N, "obs_dim": batch.obs_dim, "launch": "hipGraph" if use_graph else "eager",
+                       "envs_per_gpu": E, "evs_per_env": N, "obs_dim": batch.obs_dim, "launch": "hipGraph" if use_graph else "eager", "prime_ms": args.prime_ms,
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false>", "kernel_ms": k_ms,

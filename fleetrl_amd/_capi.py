@@ -149,6 +149,7 @@ def load_library():
     lib.fleet_reset_host.argtypes = [vp, u8p, f32p]
     lib.fleet_step_host.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
     lib.fleet_get.argtypes = [vp, C.c_int, vp]
+    lib.fleet_get_dev.argtypes = [vp, C.c_int, vp]
     lib.fleet_get_dist_factor.argtypes = [vp, vp]
     lib.fleet_check_errors.argtypes = [vp]
     lib.fleet_timer_start.argtypes = [vp]
@@ -157,8 +158,8 @@ def load_library():
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
-                 "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start", "fleet_timer_stop",
-                 "fleet_run_tape_dev", "fleet_time_steps_dev"):
+                 "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
+                 "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -168,6 +169,6 @@ EXPORTED_SYMBOLS = (
     "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_synchronize",
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev",
     "fleet_set_night_policy", "fleet_reset_host",
-    "fleet_step_host", "fleet_get", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
+    "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev",
 )

@@ -145,6 +145,10 @@ class FleetBatch:
         self._check(self.lib.fleet_get(self.h, fid, out.ctypes.data))
         return out
 
+    def get_dev(self, name: str, out_ptr: int):
+        """Unpack a state field into a device buffer (asynchronous on the handle's stream); dtype/shape as `get`."""
+        self._check(self.lib.fleet_get_dev(self.h, _capi.FIELDS[name][0], out_ptr))
+
     def dist_factor(self) -> np.ndarray:
         out = np.zeros((self.E, self.N))
         self._check(self.lib.fleet_get_dist_factor(self.h, out.ctypes.data))

@@ -596,10 +596,8 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
   return FLEET_OK;
 }
 
-int fleet_get(fleet_handle h, int field, void* out) {
-  if (!h || !out) return FLEET_ERR_INVALID;
-  HIP_TRY(h, hipSetDevice(h->device));
-  const size_t E = h->d.E, EN = (size_t)h->d.E * h->d.N;
+static size_t field_bytes(const FleetDev& d, int field) {
+  const size_t E = d.E, EN = (size_t)d.E * d.N;
   size_t bytes = 0;
   switch (field) {
     case FLEET_F_SOC: case FLEET_F_SOH: case FLEET_F_SOC_DEG: case FLEET_F_TARGET_SOC: case FLEET_F_FD_CYC:
@@ -610,9 +608,29 @@ int fleet_get(fleet_handle h, int field, void* out) {
     case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
     case FLEET_F_EPISODES: bytes = E * 4; break;
     case FLEET_F_DONE: bytes = E; break;
-    default:
-      h->error = "fleet_get: unknown field";
-      return FLEET_ERR_INVALID;
+    default: break;
+  }
+  return bytes;
+}
+
+int fleet_get_dev(fleet_handle h, int field, void* out_dev) {
+  if (!h || !out_dev) return FLEET_ERR_INVALID;
+  if (!field_bytes(h->d, field)) {
+    h->error = "fleet_get_dev: unknown field";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, fleet_launch_gather_field(h->d, field, out_dev, h->stream));
+  return FLEET_OK;
+}
+
+int fleet_get(fleet_handle h, int field, void* out) {
+  if (!h || !out) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t bytes = field_bytes(h->d, field);
+  if (!bytes) {
+    h->error = "fleet_get: unknown field";
+    return FLEET_ERR_INVALID;
   }
   HIP_TRY(h, fleet_launch_gather_field(h->d, field, h->st_field, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out, h->st_field, bytes, hipMemcpyDeviceToHost, h->stream));

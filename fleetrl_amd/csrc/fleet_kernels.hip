@@ -644,6 +644,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       const HotB hb = kEarly ? hb_pre : d.hot_b[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
+      const TabX tx1 = ld_tabx(tab_t1 + c);  // the only per-lane load that depends on the time row: requested first
+      const TabRec tb1 = tx1.tb;
+      const AuxRec ar = tx1.ar;
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -670,9 +673,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       } else {
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
-      const TabX tx1 = ld_tabx(tab_t1 + c);
-      const TabRec tb1 = tx1.tb;
-      const AuxRec ar = tx1.ar;
       // Rainflow: a present EV with a non-zero action will most likely change its SOC slope bookkeeping this step;
       // touch its rainflow row now so that the (divergent, dependent) accesses of a push / cycle closure later hit
       // the cache instead of paying a memory round trip each.

@@ -221,6 +221,9 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
 
 /* ---- state access ------------------------------------------------------------------------------------- */
 int fleet_get(fleet_handle h, int field, void* out_host);
+/* same, into a DEVICE buffer and asynchronous on the handle's stream (e.g. the episode returns that a multi-GPU run
+ * all-gathers for logging, without a host round trip) */
+int fleet_get_dev(fleet_handle h, int field, void* out_dev);
 /* `FleetEnv.get_dist_factor` (:782-799): hours_needed / (hours_left + 0.001) from a fresh observation, f64 [E,N] */
 int fleet_get_dist_factor(fleet_handle h, double* out_host);
 /* raise FLEET_ERR_STATE if any env has device error bits set */

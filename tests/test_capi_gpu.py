@@ -129,3 +129,27 @@ def test_error_reporting():
     assert ei.value.status == _capi.ERR_STATE
     assert (b.get("error_bits") & _capi.DEVERR_TABLE_END).all()
     b.close()
+
+
+def test_get_dev_matches_get():
+    """fleet_get_dev unpacks a field into a device buffer; same values as the host-side fleet_get."""
+    import torch
+
+    from fleetrl_amd.batch import FleetBatch
+
+    g = load_trace("ct5_both_rainflow")
+    E = 9
+    hip = FleetBatch(params_for(g, num_envs=E), g.tables, g.time_feat)
+    hip.set_start_schedule(np.full((1, E), 7, dtype=np.int32))
+    hip.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(g.ep_steps + 3):
+        hip.step(rng.uniform(-1, 1, size=(E, g.N)).astype(np.float32))
+    dev = torch.device("cuda", 0)
+    for name, dt in (("last_ep_return", torch.float64), ("last_ep_len", torch.int32), ("soc", torch.float64), ("hours_left", torch.float32)):
+        shape = (E, g.N) if _capi.FIELDS[name][2] else (E,)
+        buf = torch.zeros(shape, device=dev, dtype=dt)
+        hip.get_dev(name, buf.data_ptr())
+        hip.synchronize()
+        np.testing.assert_array_equal(buf.cpu().numpy(), hip.get(name))
+    assert hip.get("last_ep_len").min() == g.ep_steps
