@@ -572,7 +572,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
   uint32_t err = 0;
   double reward_sum = 0.0;
   int n_done = 0;
+#ifdef FLEET_ABL_OBS_LOCAL  // diagnostic: same store instructions, (almost) no write traffic
+  float* const obs_row = obs + (size_t)(e & 63) * d.obs_dim;
+#else
   float* const obs_row = obs + (size_t)e * d.obs_dim;
+#endif
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
   const int steps = MULTI ? K : 1;
   const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
@@ -603,7 +607,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     const size_t abase = ((size_t)k * d.E + e) * N;
+#ifdef FLEET_ABL_TAB_LOCAL  // diagnostic: same loads, table rows of 64 time steps only (cache resident)
+    const TabX* __restrict__ tab_t1 = d.tab + (size_t)(t1 & 63) * N;
+#else
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
+#endif
 
     const float tail_first = write_step_obs ? tail_load<G>(d, t1, g) : 0.0f;  // consumed after the lane loop
 
