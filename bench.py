@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tape-len", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (with --device-index) only exists to smoke-test the multi-rank control "
+                         "flow with several ranks on ONE GPU, which RCCL refuses")
+    ap.add_argument("--device-index", type=int, default=None, help="GPU to use instead of LOCAL_RANK (test hook, see --backend)")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
     ap.add_argument("--deg", default="rainflow", choices=["none", "linear", "rainflow"],
                     help="degradation model (default rainflow = the BASELINE workload; others are diagnostics)")
@@ -130,10 +134,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.device_index is not None:
+        local_rank = args.device_index
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     E, N = args.envs_per_gpu, args.evs
     cfg = bench_config(E, N, args.use_case)
@@ -171,7 +181,7 @@ def main():
     batch.synchronize()
     ret = torch.zeros(E, device=dev, dtype=torch.float64)
     ln = torch.zeros(E, device=dev, dtype=torch.int32)
-    gather_episode_stats(ret, ln)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
+    gather_episode_stats(ret.to(cdev), ln.to(cdev))  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
 
     def barrier():
         torch.cuda.synchronize()
@@ -188,11 +198,11 @@ def main():
     batch.get_dev("last_ep_return", ret.data_ptr())  # device-side unpack, no host round trip
     batch.get_dev("last_ep_len", ln.data_ptr())
     batch.synchronize()
-    r_all, n_all = gather_episode_stats(ret, ln)
+    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev))
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        w = torch.tensor([wall], device=dev, dtype=torch.float64)
+        w = torch.tensor([wall], device=cdev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     batch.check_errors()
