@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -52,6 +52,7 @@ _I32_FIELDS = (
     "abi_version", "struct_bytes", "num_envs", "num_cars", "table_rows", "episode_steps", "price_lookahead",
     "bl_pv_lookahead", "steps_per_hour", "hour_phase", "include_building", "include_pv", "aux", "normalize",
     "is_caretaker", "deg_mode", "picker_mode", "start_lo", "start_hi", "auto_reset", "env_id_offset", "log_data",
+    "real_time", "reserved0",
 )
 _F64_FIELDS = (
     "dt", "evse_power", "obc_max_power", "batt_cap_nominal", "init_battery_cap", "grid_connection",
@@ -130,6 +131,13 @@ def load_library():
     if not os.path.isfile(path):
         raise FleetHipError(ERR_NODEVICE, f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 and only finds the GPU if that copy is the one
+    # that gets loaded; loading this library first would pull in /opt/rocm's copy instead ("No HIP GPUs are available"
+    # on the first torch.cuda call afterwards).  Importing torch first makes the order deterministic.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure C-ABI use without PyTorch: the system runtime is the only one
+        pass
     lib = C.CDLL(path)
     vp, i32p, u8p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p
     lib.fleet_obs_dim.argtypes = [C.POINTER(FleetParams)]

@@ -105,6 +105,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
   if (p->normalize && p->include_pv && !p->include_building)
     return "normalize with pv but without building load crashes in the reference (quirk Q4); unsupported";
+  if (p->real_time && p->log_data) return "log_data is not available with real_time (only the last skipped row would be logged)";
   if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > p->table_rows - 1) return "start range outside the table";
   if (!t->there || !t->time_left || !t->soc_on_return || !t->delu || !t->tariff || !t->prc || !t->trc || !t->load ||
       !t->pv || !t->hour || !t->minute || !t->month || !t->weekday)
@@ -273,6 +274,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.tail_stride = ((d.tail_a_len + d.tail_b_len + 3) / 4) * 4;
   d.aux = p->aux; d.normalize = p->normalize; d.is_caretaker = p->is_caretaker; d.deg_mode = p->deg_mode;
   d.auto_reset = p->auto_reset;
+  d.real_time = p->real_time ? 1 : 0;
   d.dt = p->dt; d.evse_power = p->evse_power;
   d.p_avail = p->obc_max_power < p->evse_power ? p->obc_max_power : p->evse_power;  // min([obc, evse]) ev_charger.py:95
   d.init_cap = p->init_battery_cap; d.grid_connection = p->grid_connection;
@@ -500,6 +502,10 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
     h->error = "fleet_step_many_dev needs auto_reset = 1";
     return FLEET_ERR_INVALID;
   }
+  if (h->d.real_time) {
+    h->error = "fleet_step_many_dev is not available with real_time = 1 (each launch already spans a variable number of rows)";
+    return FLEET_ERR_INVALID;
+  }
   HIP_TRY(h, hipSetDevice(h->device));
   if (K == 1) {
     // K == 1 writes per-step reward/done; keep the many-step contract (sum / count) by using the staging done buffer
@@ -545,6 +551,10 @@ int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, doub
   }
   if (!h->d.auto_reset) {
     h->error = "fleet_rollout_policy_dev needs auto_reset = 1";
+    return FLEET_ERR_INVALID;
+  }
+  if (h->d.real_time) {
+    h->error = "fleet_rollout_policy_dev is not available with real_time = 1";
     return FLEET_ERR_INVALID;
   }
   HIP_TRY(h, hipSetDevice(h->device));

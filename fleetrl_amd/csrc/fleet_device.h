@@ -151,6 +151,7 @@ struct FleetDev {
   int tail_b_len;   // evse|grid|avail|pavg|6 time features   (obs offset 2N + tail_a_len + 5N), 0 if !aux
   int tail_stride;  // floats per tail row (tail_a then tail_b, padded to a multiple of 4)
   int aux, normalize, is_caretaker, deg_mode, auto_reset;
+  int real_time;    // event-skipping step (multi-step kernel only)
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;

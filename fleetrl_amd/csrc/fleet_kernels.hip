@@ -72,6 +72,15 @@ __device__ __forceinline__ double dpp_add(double v) {
 // Sum over the G lanes of an aligned group; the result is valid in the LAST lane of the group.
 // row_shr:1/2/4/8 (0x111..0x118) scan inside a 16-lane row, row_bcast:15 (0x142) and row_bcast:31 (0x143)
 // carry row totals across rows.  All 64 lanes must execute this (uniform control flow).
+// true in every lane of the group if `v` holds in any of its lanes (real_time event test)
+template <int G>
+__device__ __forceinline__ bool group_any(bool v) {
+  const unsigned long long m = __ballot(v);
+  if (G == 64) return m != 0ull;
+  const int base = (int)(threadIdx.x % 64) & ~(G - 1);
+  return ((m >> base) & ((1ull << (G % 64)) - 1ull)) != 0ull;
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum_to_last(double v) {
   if (G >= 2) v = dpp_add<0x111, 0xF>(v);
@@ -587,7 +596,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     if (G == 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
   }
 
-  for (int k = 0; k < steps; ++k) {
+  // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
+  // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
+  const bool rt = MULTI && (d.real_time != 0);
+  double last_rew = 0.0;
+  bool last_done = false;
+  for (int k = 0; rt || k < steps; ++k) {
     const int t = r.t;
     int t1 = t + 1;  // :508
     if (t1 > d.T - 1) { t1 = d.T - 1; err |= FLEET_DEVERR_TABLE_END; }
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
-    const size_t abase = ((size_t)k * d.E + e) * N;
+    const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
 #ifdef FLEET_ABL_TAB_LOCAL  // diagnostic: same loads, table rows of 64 time steps only (cache resident)
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)(t1 & 63) * N;
 #else
@@ -645,6 +659,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     }
 
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
+    bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
@@ -719,6 +734,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
       const double en = present ? en_p : 0.0;
       rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
+      if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
       soc = soc + (pos ? en * d.eta_c : en) / cap;  // :128 / :189
       const double grid_e = fmax(en - ph.pv_share, 0.0);  // :142 (charging only)
       cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
@@ -728,6 +744,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
+      // departure :532, arrival :603, low state of health :615 are events too
+      if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (hb.soh <= 0.9);
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
         const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
@@ -812,6 +830,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
         const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
         rew += pen;
         penalty_record += pen;
+        if (MULTI) ev_lane = true;  // :499
       }
       if (d.log_env && env_ok) {
         d.log_env[2 * (size_t)e] = over;          // grid = abs(overload_amount) (:660)
@@ -820,6 +839,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       ep_return += rew;  // :637
       ep_len += 1;
       reward_sum += rew;
+      last_rew = rew;
       if (env_ok) {
         d.env[e].cashflow = cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
         if (!MULTI) {
@@ -874,6 +894,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
         penalty_record = 0.0;
       }
     }
+    if (rt) {
+      // EventManager.check_event (event_manager.py:16-31): the advanced row's clock minute == 15 is an event of its own;
+      // the end of the episode is one (:629); running off the table ends the loop (the reference would raise there)
+      last_done = is_done;
+      const bool minute15 = (d.cold->tab_hm[t1] & 255) == 15;
+      if (group_any<G>(ev_lane) || is_done || minute15 || (t + 1 > d.T - 1)) break;
+    }
   }
 
   if (leader && env_ok) {
@@ -883,7 +910,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     er->ep_len = ep_len;
     er->penalty_record = penalty_record;
     if (MULTI) {
-      reward[e] = reward_sum;
+      reward[e] = rt ? last_rew : reward_sum;
+      if (rt && done) done[e] = last_done ? 1 : 0;
       if (done_count) done_count[e] = n_done;
       if (act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
@@ -955,7 +983,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED);
+  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, d, actions, f64, 1, obs, reward,

@@ -54,8 +54,9 @@ def validate_supported(rc: ResolvedConfig) -> None:
     if rc.normalize_in_env and rc.include_pv and not rc.include_building:
         raise ValueError("normalize_in_env with include_pv and without include_building crashes in the reference "
                          "(oracle_normalization.py:121); unsupported")
-    if rc.real_time:
-        raise ValueError("real_time=True (event-skipping loop, irregular dt) is not built yet (DESIGN.md 'next rows')")
+    if rc.real_time and bool(rc.raw.get("log_data", False)):
+        raise ValueError("log_data with real_time=True is not supported: the reference logs every skipped row "
+                         "(fleet_environment.py:677-690), the device keeps only the last one")
     if rc.deg_mode == DEG_RAINFLOW and rc.init_soh != 1.0:
         raise ValueError("rainflow/SEI degradation with init_soh != 1.0 is ill-defined in the reference "
                          "(rainflow_sei_degradation.py:184); unsupported")
@@ -159,6 +160,14 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     p.auto_reset = int(auto_reset)
     p.env_id_offset = int(env_id_offset)
     p.log_data = int(bool(rc.raw.get("log_data", False)))
+    if rc.real_time:
+        # event-skipping needs a regular grid here: the reference's per-row dt (`get_next_dt`, :994-1008) is tabulated
+        # as one constant, and the hourly look-ahead blocks are indexed arithmetically
+        step = np.diff(tables.dates.astype("datetime64[s]").astype(np.int64))
+        if step.size and not np.all(step == rc.minutes * 60):
+            raise ValueError("real_time=True on an irregular time grid is not supported (rows must be "
+                             f"{rc.minutes} min apart); resample the schedule first")
+    p.real_time = int(rc.real_time)
     s = rc.seed if seed is None else seed
     p.seed = int(s) if s is not None else 0
     p.dt = rc.dt

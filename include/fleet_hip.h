@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 1
+#define FLEET_ABI_VERSION 2
 
 /* status codes */
 #define FLEET_OK 0
@@ -94,6 +94,10 @@ typedef struct FleetParams {
   int32_t log_data;         /* 1: keep the per-step quantities of the reference's DataLogger (utils/data_logger/data_logger.py)
                                that are not step outputs -- grid overload, SOC missing at departure, per-EV energy -- for
                                FLEET_F_LOG_*; 0: skip them */
+  int32_t real_time;        /* 1: event-skipping step (fleet_environment.py:453,692-699, event_manager.py:16-31): the same
+                               action is applied row after row until a relevant event (departure, arrival, penalty,
+                               overload, episode end, clock minute 15); regular time grids only */
+  int32_t reserved0;
   uint64_t seed;            /* Philox key for the random/eval picker */
 
   double dt;                /* hours per step (time_config.py:24) */

@@ -247,7 +247,137 @@ def run_config(name: str):
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), window rows [{w0},{w1})", flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# real_time (event-skipping) traces: one agent step spans a variable number of table rows, an episode a variable
+# number of agent steps -> own trace layout (tests/golden/rttrace_<name>.npz, read by tests/test_real_time_*.py)
+# ---------------------------------------------------------------------------------------------------------------
+RT_CONFIGS = {
+    # name -> (overrides, n_evs, E, episodes)
+    "ct5_both_rainflow": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                               calculate_degradation=True, deg_emp=False, episode_length=48, real_time=True), 5, 2, 2),
+    "lmd3_price_linear": (dict(use_case="lmd", include_building=False, include_pv=False, calculate_degradation=True,
+                               deg_emp=True, episode_length=24, real_time=True), 3, 2, 2),
+    "ut2_both_norm_nodeg": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
+                                 normalize_in_env=True, calculate_degradation=False, episode_length=24, real_time=True), 2, 2, 2),
+}
+
+
+def make_actions_rt(rng: np.random.Generator, steps: int, n: int) -> np.ndarray:
+    """Quiet actions (many exact zeros, small charging powers) so that rows really get skipped, with occasional bursts that
+    trigger the penalty events."""
+    a = rng.uniform(0.0, 0.5, size=(steps, n))
+    a[rng.random((steps, n)) < 0.55] = 0.0
+    burst = rng.random(steps) < 0.12
+    a[burst] = rng.uniform(-1, 1, size=(int(burst.sum()), n))
+    return a.astype(np.float32)
+
+
+def run_config_rt(name: str):
+    import json
+
+    from oracle.ref_harness import base_config
+
+    ov, n_evs, E, episodes = RT_CONFIGS[name]
+    ov = dict(ov)
+    dp, sched = stacked_inputs_dir(ov["use_case"], n_evs)
+    ov.update(data_path=dp, schedule_name=sched)
+    ov.setdefault("target_soc", 0.85)
+    rng = np.random.default_rng(sum(map(ord, "rt_" + name)))
+    ep_rows = ov["episode_length"] * 4
+    cap = ep_rows * episodes  # an agent step spans >= 1 row
+    rec, scalars, db0 = None, {}, None
+    starts = np.zeros((episodes, E), dtype=np.int32)
+    t0 = time.time()
+    for e in range(E):
+        env = make_ref_env(ov)
+        N = int(env.num_cars)
+        T = len(env.db) // N
+        if rec is None:
+            D = env.observation_space.shape[0]
+            rec = dict(
+                actions=np.zeros((E, cap, N), np.float32), obs=np.zeros((E, cap, D), np.float32),
+                reset_obs=np.zeros((E, episodes, D), np.float32), n_steps=np.zeros((E, episodes), np.int32),
+                reward=np.zeros((E, cap)), done=np.zeros((E, cap), np.uint8), cashflow=np.zeros((E, cap)),
+                ep_return=np.zeros((E, cap)), soc=np.zeros((E, cap, N)), hours_left=np.zeros((E, cap, N)),
+                soh=np.zeros((E, cap, N)), soc_deg=np.zeros((E, cap, N)), time_idx=np.zeros((E, cap), np.int32),
+                rf_len=np.zeros((E, episodes, N), np.int32), fd_cyc=np.zeros((E, episodes, N)), sei_l=np.zeros((E, episodes, N)),
+            )
+            db0 = env.db
+            lc = env.load_calculation
+            scalars = dict(grid_connection=lc.grid_connection, evse_power=lc.evse_max_power, batt_cap_nominal=lc.batt_cap,
+                           init_battery_cap=env.ev_config.init_battery_cap, price_multiplier=env.score_config.price_multiplier,
+                           obs_dim=D, num_cars=N, table_rows_full=T)
+        dates0 = env.db["date"].values[:T]
+        acts = make_actions_rt(rng, cap, N)
+        rec["actions"][e] = acts
+        if e == 0:
+            span0 = int(rng.integers(0, T - 1 - 60 * 96 - 20 * 96))
+        starts[:, e] = rng.integers(span0, span0 + 20 * 96, size=episodes)
+        k = 0
+        for ep in range(episodes):
+            set_static_start(env, int(starts[ep, e]))
+            obs, _ = env.reset()
+            rec["reset_obs"][e, ep] = obs
+            d, n = False, 0
+            while not d:
+                obs, r, d, _tr, _info = env.step(acts[k].astype(np.float64))
+                rec["obs"][e, k] = obs
+                rec["reward"][e, k] = r
+                rec["done"][e, k] = d
+                rec["cashflow"][e, k] = env.episode.current_charging_expense
+                rec["ep_return"][e, k] = env.episode.cumulative_reward
+                rec["soc"][e, k] = np.asarray(env.episode.soc, dtype=np.float64)
+                rec["hours_left"][e, k] = np.asarray(env.episode.hours_left, dtype=np.float64)
+                rec["soh"][e, k] = np.asarray(env.episode.soh, dtype=np.float64)
+                rec["soc_deg"][e, k] = np.asarray(env.episode.soc_deg, dtype=np.float64)
+                rec["time_idx"][e, k] = int(np.searchsorted(dates0, np.datetime64(env.episode.time)))
+                k += 1
+                n += 1
+            rec["n_steps"][e, ep] = n
+            if ov["calculate_degradation"] and not ov["deg_emp"]:
+                sd = env.sei_deg
+                rec["rf_len"][e, ep] = sd.rainflow_length
+                rec["fd_cyc"][e, ep] = sd.fd_cyc
+                rec["sei_l"][e, ep] = sd.l
+        print(f"  rt {name}: env {e + 1}/{E}: {rec['n_steps'][e].tolist()} agent steps for {ep_rows} rows per episode "
+              f"({time.time() - t0:.0f}s)", flush=True)
+    N, T = scalars["num_cars"], scalars["table_rows_full"]
+    L2 = (ov.get("price_lookahead", 8) + 2) * 4 + 1
+    w0 = (int(starts.min()) // 96) * 96
+    w1 = min(T, int(starts.max()) + ep_rows + L2 + 1)
+    col = lambda c: db0[c].values.reshape(N, T).T[w0:w1]  # noqa: E731
+    one = lambda c: db0[c].values[:T][w0:w1] if c in db0 else np.zeros(w1 - w0)  # noqa: E731
+    tables = dict(dates=db0["date"].values[:T][w0:w1].astype("datetime64[s]").astype(np.int64), there=col("There").astype(np.uint8),
+                  time_left=col("time_left").astype(np.float64), soc_on_return=col("SOC_on_return").astype(np.float64),
+                  delu=one("DELU"), tariff=one("tariff"), prc=one("price_reward_curve"), trc=one("tariff_reward_curve"),
+                  load=one("load"), pv=one("pv"))
+    ext = dict(max_time_left=float(np.nanmax(db0["time_left"].values)), max_delu=float(np.nanmax(db0["DELU"].values)),
+               min_delu=float(np.nanmin(db0["DELU"].values)), max_tariff=float(np.nanmax(db0["tariff"].values)),
+               min_tariff=float(np.nanmin(db0["tariff"].values)),
+               max_load=float(np.nanmax(db0["load"].values)) if "load" in db0 else 0.0,
+               max_pv=float(np.nanmax(db0["pv"].values)) if "pv" in db0 else 0.0)
+    scalars.update({f"ext_{k}": v for k, v in ext.items()})
+    scalars["window_row0"] = w0
+    full_cfg = base_config()
+    full_cfg.update(ov)
+    full_cfg["data_path"] = "<not shipped>"
+    used = int(rec["n_steps"].sum(axis=1).max())
+    out = {f"tab_{k}": v for k, v in tables.items()}
+    out.update({f"sc_{k}": np.asarray(v) for k, v in scalars.items()})
+    out["cfg_json"] = np.asarray(json.dumps(full_cfg))
+    out.update({k: (v[:, :used] if v.shape[1:2] == (cap,) else v) for k, v in rec.items()})
+    out["starts"] = starts - w0
+    out["time_idx"] = out["time_idx"] - w0
+    path = os.path.join(GOLDEN, f"rttrace_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"rt {name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), window rows [{w0},{w1})", flush=True)
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CONFIGS)
-    for n in names:
-        run_config(n)
+    args = sys.argv[1:]
+    if args and args[0] == "rt":
+        for n in args[1:] or list(RT_CONFIGS):
+            run_config_rt(n)
+    else:
+        for n in args or list(CONFIGS):
+            run_config(n)

@@ -21,8 +21,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRACE_NAMES = sorted(os.path.basename(p)[len("trace_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN_DIR, "trace_*.npz")))
 
 
-def load_trace(name: str) -> SimpleNamespace:
-    z = np.load(os.path.join(GOLDEN_DIR, f"trace_{name}.npz"), allow_pickle=False)
+RT_TRACE_NAMES = sorted(os.path.basename(p)[len("rttrace_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN_DIR, "rttrace_*.npz")))
+
+
+def load_trace(name: str, prefix: str = "trace_") -> SimpleNamespace:
+    z = np.load(os.path.join(GOLDEN_DIR, f"{prefix}{name}.npz"), allow_pickle=False)
     g = SimpleNamespace(**{k: z[k] for k in z.files})
     g.name = name
     g.cfg = json.loads(str(z["cfg_json"]))
@@ -118,4 +121,63 @@ def replay(g, engine, *, float_rtol=1e-9, obs_exact=True, check_sei=True, env_ma
                         np.testing.assert_allclose(engine.dist_factor(), g.dist_factor[env_map, ep + 1], rtol=1e-12, atol=0)
             k += 1
     assert not np.any(engine.get("error_bits")), "device/oracle error bits set"
+    return worst
+
+
+def load_rt_trace(name: str) -> SimpleNamespace:
+    """real_time (event-skipping) trace, oracle/gen_golden.py `run_config_rt`: per env a variable number of agent steps
+    per episode (`n_steps[E, episodes]`), arrays indexed by the env's running agent-step count."""
+    g = load_trace(name, prefix="rttrace_")
+    g.ep_rows = g.rc.episode_length * (60 // g.rc.minutes)
+    g.total_e = g.n_steps.sum(axis=1)  # agent steps recorded per env
+    return g
+
+
+def replay_rt(g, engine, *, float_rtol=1e-9, obs_exact=True):
+    """Lock-step replay of a real_time trace on an auto-resetting engine with E == g.E envs: env e is compared while its
+    running step count is below g.total_e[e]; afterwards it keeps stepping (next schedule entry) and is ignored."""
+    E = g.E
+    assert engine.E == E
+    engine.set_start_schedule(g.starts)
+    obs = engine.reset()
+    cmp = (lambda a, b, m: np.testing.assert_array_equal(a, b, err_msg=m)) if obs_exact else \
+          (lambda a, b, m: np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6, err_msg=m))
+    cmp(obs, g.reset_obs[:, 0], "reset obs, episode 0")
+    ep_end = np.cumsum(g.n_steps, axis=1)  # [E, episodes] running index after each episode's last step
+    episode = np.zeros(E, dtype=np.int64)
+    worst = dict(reward=0.0, soc=0.0, soh=0.0)
+    rows_seen = 0
+    for k in range(int(g.total_e.max())):
+        live = k < g.total_e
+        obs, rew, done, term = engine.step(g.actions[:, k])
+        t_idx, soc, soh, hl, cash = (engine.get(n) for n in ("time_idx", "soc", "soh", "hours_left", "cashflow"))
+        for e in np.nonzero(live)[0]:
+            what = f"env {e}, agent step {k}"
+            assert bool(done[e]) == bool(g.done[e, k]), f"done flag, {what}"
+            np.testing.assert_allclose(rew[e], g.reward[e, k], rtol=float_rtol, atol=1e-12, err_msg=f"reward, {what}")
+            np.testing.assert_allclose(cash[e], g.cashflow[e, k], rtol=float_rtol, atol=1e-13, err_msg=f"cashflow, {what}")
+            worst["reward"] = max(worst["reward"], rel_err(rew[e], g.reward[e, k]))
+            if g.done[e, k]:
+                assert k + 1 == ep_end[e, episode[e]], what
+                cmp(term[e], g.obs[e, k], f"terminal obs, {what}")
+                if g.rc.deg_mode == 2:
+                    np.testing.assert_array_equal(engine.get("rf_len")[e], g.rf_len[e, episode[e]], err_msg=what)
+                    np.testing.assert_allclose(engine.get("fd_cyc")[e], g.fd_cyc[e, episode[e]], rtol=1e-9, atol=1e-18)
+                    np.testing.assert_allclose(engine.get("sei_l")[e], g.sei_l[e, episode[e]], rtol=1e-9, atol=1e-18)
+                episode[e] += 1
+                if episode[e] < g.episodes:
+                    cmp(obs[e], g.reset_obs[e, episode[e]], f"reset obs after {what}")
+            else:
+                cmp(obs[e], g.obs[e, k], f"obs, {what}")
+                assert t_idx[e] == g.time_idx[e, k], f"time row, {what}"
+                np.testing.assert_array_equal(hl[e].astype(np.float64), g.hours_left[e, k], err_msg=what)
+                np.testing.assert_allclose(soc[e], g.soc[e, k], rtol=float_rtol, atol=1e-15, err_msg=f"soc, {what}")
+                np.testing.assert_allclose(soh[e], g.soh[e, k], rtol=float_rtol, atol=0, err_msg=f"soh, {what}")
+                np.testing.assert_allclose(engine.get("ep_return")[e], g.ep_return[e, k], rtol=float_rtol, atol=1e-11,
+                                           err_msg=f"episode return (sums the skipped rows too), {what}")
+                worst["soc"] = max(worst["soc"], rel_err(soc[e], g.soc[e, k]))
+                worst["soh"] = max(worst["soh"], rel_err(soh[e], g.soh[e, k]))
+        rows_seen += 1
+    assert not np.any(engine.get("error_bits")), "device/oracle error bits set"
+    assert np.all(g.n_steps < g.ep_rows), "the trace must actually skip rows"
     return worst

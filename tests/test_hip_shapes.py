@@ -19,7 +19,7 @@ def _tables(uc, n):
     return _TABLES[(uc, n)]
 
 
-def _cfg(uc, deg, norm, aux=True, building=True, pv=True, episode_length=24):
+def _cfg(uc, deg, norm, aux=True, building=True, pv=True, episode_length=24, real_time=False):
     return {
         "data_path": "<synthetic>", "use_case": uc, "building_name": None, "price_name": None, "tariff_name": None,
         "schedule_name": None, "pv_name": None, "seed": 0, "include_building": building, "include_pv": pv,
@@ -28,16 +28,16 @@ def _cfg(uc, deg, norm, aux=True, building=True, pv=True, episode_length=24):
         "normalize_in_env": norm, "aux": aux, "ignore_price_reward": False, "ignore_overloading_penalty": False,
         "ignore_invalid_penalty": False, "ignore_overcharging_penalty": False, "gen_schedule": False,
         "gen_start_date": None, "gen_end_date": None, "gen_name": None, "gen_n_evs": 1, "spot_markup": None,
-        "spot_mul": None, "feed_in_ded": None, "real_time": False, "episode_length": episode_length, "target_soc": 0.85,
+        "spot_mul": None, "feed_in_ded": None, "real_time": real_time, "episode_length": episode_length, "target_soc": 0.85,
     }
 
 
-def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=True, seed=0):
+def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=True, seed=0, real_time=False):
     from fleetrl_amd.batch import FleetBatch
     from oracle.fleet_oracle import OracleBatch
 
     tb = _tables(uc, n_evs)
-    rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv))
+    rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv, real_time=real_time))
     p = make_params(rc, tb, num_envs, seed=seed + 1)
     tf = time_features(tb)
     hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=4)
@@ -50,6 +50,9 @@ def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=
         a = rng.uniform(-1, 1, size=(num_envs, n_evs)) if mode == 0 else rng.uniform(-0.2, 1, size=(num_envs, n_evs)) \
             if mode == 1 else np.full((num_envs, n_evs), 1.0)
         a[rng.random(a.shape) < 0.15] = 0.0
+        if real_time:  # quiet envs so that rows are really skipped: half of the envs idle in two steps out of three
+            quiet = (np.arange(num_envs) % 2 == 0) & (s % 3 != 0)
+            a[quiet] = 0.0
         a = a.astype(np.float32)
         oh, rh, dh, th = hip.step(a)
         oc, rc_, dc, tc = cpu.step(a)
@@ -136,3 +139,15 @@ def test_float64_actions_and_static_eval_pickers():
         np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))
         hip.close()
         cpu.close()
+
+
+@pytest.mark.parametrize("uc,n_evs,num_envs,deg,norm", [
+    ("ct", 50, 37, "rainflow", False),   # one wavefront per env: wave-uniform event test
+    ("lmd", 5, 67, "linear", True),      # 8 lanes per env: envs of one wavefront leave the skipping loop at different rows
+    ("ut", 1, 130, "none", False),       # one lane per env
+    ("ct", 130, 9, "rainflow", False),   # several EVs per lane
+])
+def test_real_time_event_skipping_matches_oracle(uc, n_evs, num_envs, deg, norm):
+    """real_time=True: one launch repeats the step with the same action until a relevant event (fleet_environment.py:453,
+    692-699); envs advance by different numbers of rows per step."""
+    _compare(uc, n_evs, num_envs, deg, norm, steps=260 if n_evs < 100 else 150, seed=11, real_time=True)
