@@ -252,8 +252,11 @@ def main():
                          "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_env_step": bytes_step, "bytes_per_launch": bytes_step * E,
                          "kernel_ms_event_pair_per_launch": float(np.mean(per))},
+            # K steps per launch: only the last step's observation is part of the result (and written), so the
+            # algorithmic bytes per env-step are smaller by the observation row for K-1 of the K steps
             "step_many": {"K": K, "env_steps_per_s": E * K * reps / (many_ms * 1e-3),
-                          "GBps": bytes_step * E * K * reps / (many_ms * 1e-3) / 1e9},
+                          "algorithmic_bytes_per_env_step": bytes_step - 4 * batch.obs_dim * (K - 1) / K,
+                          "GBps": (bytes_step - 4 * batch.obs_dim * (K - 1) / K) * E * K * reps / (many_ms * 1e-3) / 1e9},
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
         if not args.no_cpu_baseline:

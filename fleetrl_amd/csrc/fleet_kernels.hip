@@ -609,7 +609,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
     const bool resets = is_done && d.auto_reset;
     // where this step's observation goes: with vec-env auto-reset the terminal observation is reported aside
     float* const step_row = resets ? term_row : obs_row;
+    // intermediate steps of a K-step launch only need their observation when the episode ends (terminal observation)
+#ifdef FLEET_OBS_EVERY_STEP
     const bool write_step_obs = env_ok && (step_row != nullptr);
+#else
+    const bool write_step_obs = env_ok && (step_row != nullptr) && (!MULTI || rt || resets || k == steps - 1);
+#endif
 
     FLEET_STAMP(1);
     // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
