@@ -49,6 +49,9 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
+#ifndef FLEET_SINGLE_WAVES
+#define FLEET_SINGLE_WAVES 4  // same for the single-step kernel
+#endif
 #ifndef FLEET_MULTI_WAVES
 #define FLEET_MULTI_WAVES 2  // waves per SIMD the multi-step kernel is compiled for (register budget 512 / this)
 #endif
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI, bool WIDE>
-__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
+__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
@@ -701,16 +704,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       } else {
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
-      // Rainflow: a present EV with a non-zero action will most likely change its SOC slope bookkeeping this step;
-      // touch its rainflow row now so that the (divergent, dependent) accesses of a push / cycle closure later hit
-      // the cache instead of paying a memory round trip each.
-      double rf_touch = 0.0;
-      if (DEG == FLEET_DEG_RAINFLOW) {
-#ifdef FLEET_ENABLE_RF_TOUCH
-        if (HOT_THERE(hb.bits) && a != 0.0 && HOT_SGN(hb.bits) != 0) rf_touch = d.rf_rows[i * (size_t)d.rf_row_stride];
-#endif
-      }
-
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
       double soc = ha.soc;
       float hl = hb.hl;
@@ -795,7 +788,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
       }
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
-      if (DEG == FLEET_DEG_RAINFLOW) asm volatile("" ::"v"(rf_touch));  // keep the touch load alive
       FLEET_STAMP(5);
       if (env_ok) {  // whole 16-byte records, always: dense full-line stores
         HotA na;
@@ -807,7 +799,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : 4) void fleet_s
         nb.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
         st_rec16(d.hot_a + i, na);
         st_rec16(d.hot_b + i, nb);
-        if (DEG == FLEET_DEG_RAINFLOW) st_rec16(d.rf_top + i, top);
+        // the cached stack top only changes when a reversal point was pushed (then tail and/or head moved)
+        if (DEG == FLEET_DEG_RAINFLOW && (tail != HOT_TAIL(hb.bits) || head != HOT_HEAD(hb.bits))) st_rec16(d.rf_top + i, top);
       }
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
