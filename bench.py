@@ -259,7 +259,7 @@ def main():
                           "GBps": (bytes_step - 4 * batch.obs_dim * (K - 1) / K) * E * K * reps / (many_ms * 1e-3) / 1e9},
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run item (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(params, tables, tf, N)
     batch.close()
     if world > 1:
