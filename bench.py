@@ -181,7 +181,7 @@ def main():
     batch.synchronize()
     ret = torch.zeros(E, device=dev, dtype=torch.float64)
     ln = torch.zeros(E, device=dev, dtype=torch.int32)
-    gather_episode_stats(ret.to(cdev), ln.to(cdev))  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
+    gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,7 +198,7 @@ def main():
     batch.get_dev("last_ep_return", ret.data_ptr())  # device-side unpack, no host round trip
     batch.get_dev("last_ep_len", ln.data_ptr())
     batch.synchronize()
-    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev))
+    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:

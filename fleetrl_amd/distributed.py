@@ -24,10 +24,12 @@ def shard_range(total_envs: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_episode_stats(returns, lengths, group=None):
+def gather_episode_stats(returns, lengths, group=None, equal_shards: bool = False):
     """All-gather per-rank `returns` f64[E_r] and `lengths` i32[E_r] into global arrays ordered by env id.
     Accepts torch tensors on the collective's device (GPU for nccl/RCCL, CPU for gloo) or NumPy arrays (CPU).
-    Ranks may hold different numbers of envs (padded to the maximum for the collective, trimmed afterwards)."""
+    Ranks may hold different numbers of envs (padded to the maximum for the collective, trimmed afterwards);
+    `equal_shards=True` promises equal counts and does the whole exchange in ONE collective (returns and lengths packed
+    into one float64 buffer: episode lengths are exact in float64)."""
     import torch
     import torch.distributed as dist
 
@@ -37,6 +39,15 @@ def gather_episode_stats(returns, lengths, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return (r.numpy(), n.numpy()) if as_numpy else (r, n)
     world = dist.get_world_size(group)
+    if equal_shards:
+        m = r.numel()
+        packed = torch.cat([r, n.to(torch.float64)])
+        out = torch.empty(world * 2 * m, dtype=torch.float64, device=r.device)
+        dist.all_gather_into_tensor(out, packed, group=group)
+        out = out.view(world, 2, m)
+        r_all = out[:, 0, :].reshape(-1)
+        n_all = out[:, 1, :].reshape(-1).to(torch.int32)
+        return (r_all.cpu().numpy(), n_all.cpu().numpy()) if as_numpy else (r_all, n_all)
     count = torch.tensor([r.numel()], dtype=torch.int64, device=r.device)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count, group=group)

@@ -48,6 +48,10 @@ def _run_shard(rank, world, total_envs, steps, port, out_dir):
     for s in range(steps):
         eng.step(acts[s, lo:hi])
     r_all, n_all = gather_episode_stats(eng.get("last_ep_return"), eng.get("last_ep_len"))
+    if total_envs % world == 0:  # the one-collective path bench.py uses (equal shards) gives the same arrays
+        r2, n2 = gather_episode_stats(eng.get("last_ep_return"), eng.get("last_ep_len"), equal_shards=True)
+        np.testing.assert_array_equal(r2, r_all)
+        np.testing.assert_array_equal(n2, n_all)
     if rank == 0:
         np.savez(os.path.join(out_dir, f"w{world}.npz"), r=r_all, n=n_all)
     dist.barrier()
