@@ -531,7 +531,13 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI, bool WIDE>
-__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(FleetDev d, const void* __restrict__ actions, int act_mode, int K,
+__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(
+    // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
+    // fleetrl_amd/build.py): what the first loads of a wavefront need -- its env record, its lanes' state records and action
+    // -- is passed here once more, ahead of the argument block, so that those loads do not wait for an argument fetch.
+    EnvRec* __restrict__ p_env, const HotA* __restrict__ p_hot_a, const HotB* __restrict__ p_hot_b, const RfTop* __restrict__ p_rf_top,
+    const void* __restrict__ p_actions, int p_E, int p_N,
+    FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
@@ -539,13 +545,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   if (d.E > 0) return;
 #endif
   FLEET_STAMP(0);
-  const int N = d.N;
+  const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
   int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
   if (G == 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
-  const bool env_ok = e_raw < d.E;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
-  const int e = env_ok ? e_raw : d.E - 1;
+  const bool env_ok = e_raw < E_;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
+  const int e = env_ok ? e_raw : E_ - 1;
   const size_t EN = (size_t)d.E * N;
 
   // One launch = one step and one EV per lane (N <= G): the lane's state records and its action do not depend on the
@@ -559,14 +565,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   double a64_pre = 0.0;
   if (kEarly && g < N) {
     const size_t i0 = (size_t)e * N + g;
-    ha_pre = d.hot_a[i0];
-    hb_pre = d.hot_b[i0];
-    if (DEG == FLEET_DEG_RAINFLOW) top_pre = d.rf_top[i0];
-    if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)actions)[i0];
-    else a32_pre = ((const float*)actions)[i0];
+    ha_pre = p_hot_a[i0];
+    hb_pre = p_hot_b[i0];
+    if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
+    if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)p_actions)[i0];
+    else a32_pre = ((const float*)p_actions)[i0];
   }
 
-  EnvHead r = d.env[e].h;
+  EnvHead r = p_env[e].h;
   if (G == 64) {
     r.t = __builtin_amdgcn_readfirstlane(r.t);
     r.t_end = __builtin_amdgcn_readfirstlane(r.t_end);
@@ -981,20 +987,21 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
+#define FLEET_PRE_ARGS d.env, d.hot_a, d.hot_b, d.rf_top, actions, d.E, d.N,  /* the preloaded leading arguments */
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, d, actions, f64, 1, obs, reward,
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,
                          done, terminal_obs, done_count);
     else
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, d, actions, f64, K, obs, reward,
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
   } else {
     if (single)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, d, actions, f64, 1, obs, reward, done,
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
                          terminal_obs, done_count);
     else
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false>), grid, block, 0, s, d, actions, f64, K, obs, reward, done,
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
                          terminal_obs, done_count);
   }
   return hipGetLastError();

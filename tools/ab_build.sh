@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.." && mkdir -p ab_variants && rm -f ab_variants/*.so
 for spec in "$@"; do
   tag="${spec%%=*}"; flags="${spec#*=}"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -shared $flags \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12 -shared $flags \
     fleetrl_amd/csrc/fleet_kernels.hip fleetrl_amd/csrc/fleet_capi.hip -o ab_variants/$tag.so &
 done
 wait; ls -la ab_variants
