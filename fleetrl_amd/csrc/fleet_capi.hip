@@ -327,8 +327,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
 
   // ---- state ----------------------------------------------------------------------------------------
   const size_t EN = (size_t)E * N;
-  if ((rc = dev_alloc(b, &d.hot_a, EN))) return rc;
-  if ((rc = dev_alloc(b, &d.hot_b, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.hot, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.soh, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.soc_deg, EN))) return rc;
   if ((rc = dev_alloc(b, &d.sei, EN))) return rc;
   if (p->log_data) {
     if ((rc = dev_alloc(b, &d.log_env, (size_t)E * 2))) return rc;
@@ -350,11 +351,10 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   {
     // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66), the initial
     // SoH and the (cleared) sticky target flags (fleet_environment.py:263)
-    std::vector<HotB> hb(EN);
-    for (auto& h : hb) { h.soh = p->init_soh; h.hl = 0; h.bits = 0; }
+    std::vector<double> soh(EN, p->init_soh);  // the hot records themselves are zero (no sticky target flag yet)
     std::vector<SeiRec> sei(EN);
     for (auto& q : sei) { q.fd_cyc = 0; q.fd_cal = 0; q.sei_soh = p->init_soh; q.sei_l = 1.0 - p->init_soh; }
-    HIP_TRY(b, hipMemcpyAsync(d.hot_b, hb.data(), EN * sizeof(HotB), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(b, hipMemcpyAsync(d.soh, soh.data(), EN * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipMemcpyAsync(d.sei, sei.data(), EN * sizeof(SeiRec), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }

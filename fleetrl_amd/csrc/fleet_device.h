@@ -2,8 +2,9 @@
 // (fleet_kernels.hip) and the host side of the C ABI (fleet_capi.hip).  gfx950 only.
 //
 // Layout rules (DESIGN.md "Data layout in HBM"):
-//   * everything a lane touches every step sits in two 16-byte half-records per (env, EV), each in its own array:
-//     one 16-byte load/store per lane and half, consecutive lanes = consecutive records, whole cache lines;
+//   * everything a lane reads AND writes every step sits in one dense 16-byte record per (env, EV): one 16-byte load /
+//     store per lane, consecutive lanes = consecutive records, whole cache lines; what changes rarely (soh, the frozen
+//     soc_deg of an absent EV) sits in planes of its own and is only written when it changes;
 //   * everything a group needs per env and step sits in ONE 64-byte record (16-byte head + leader statistics);
 //   * table values of (time row, EV) sit in one 32-byte record, the env-level observation blocks and the physics
 //     scalars of a time row in contiguous rows;
@@ -57,26 +58,29 @@ struct TabX {
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
 // ---- state ---------------------------------------------------------------------------------------------------
-// Hot state of (env e, EV c): two 16-byte halves kept in two arrays, so that every wave-level load / store of a
-// half covers whole cache lines (a 32-byte AoS record written 24 bytes at a time costs two partial writes per line).
-struct HotA {
+// Hot state of (env e, EV c): ONE dense 16-byte record read and written every step (consecutive lanes = consecutive
+// records = whole cache lines), plus two float64 planes that are NOT written every step:
+//   soh     : read every step (battery_cap = soh * init_battery_cap), written on the daily degradation row only;
+//   soc_deg : episode.soc_deg == last logged SOC sample.  While an EV is plugged in it equals `soc` after every step
+//             (fleet_environment.py:621-623), so it is only materialised while it differs -- the EV is away (or the
+//             episode started from an empty battery, :395-399) -- and the FROZEN bit says so.  Written once per trip.
+struct Hot {
   double soc;      // episode.soc
-  double soc_deg;  // episode.soc_deg == last logged SOC sample (LogDataDeg.soc_log[-1])
-};
-struct HotB {
-  double soh;      // episode.soh  (battery_cap = soh * init_battery_cap is recomputed on use)
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
   uint32_t bits;   // [12:0] rainflow stack tail, [25:13] stack head, [27:26] sign of the last SOC slope
-                   // (0 none, 1 up, 2 down), [30] There at the current time row (carried so the step needs no
-                   // table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
+                   // (0 none, 1 up, 2 down), [28] FROZEN: soc_deg lives in the soc_deg plane (else soc_deg == soc),
+                   // [30] There at the current time row (carried so the step needs no table read for it),
+                   // [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
 #define HOT_TAIL(b) ((int)((b) & 0x1FFFu))
 #define HOT_HEAD(b) ((int)(((b) >> 13) & 0x1FFFu))
 #define HOT_SGN(b) ((int)(((b) >> 26) & 3u))
+#define HOT_FROZEN(b) ((((b) >> 28) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define HOT_PACK(tail, head, sgn, there, t090) \
-  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((uint32_t)(there) << 30) | ((t090) ? 0x80000000u : 0u))
+#define HOT_PACK(tail, head, sgn, frozen, there, t090)                                                       \
+  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((frozen) ? 0x10000000u : 0u) | \
+   ((uint32_t)(there) << 30) | ((t090) ? 0x80000000u : 0u))
 
 // Env record, 64 B = one cache line: the 16-byte head every lane of the group needs (wave-uniform for G == 64),
 // followed by the episode statistics only the group's leader lane touches.  One pointer, one line per env and step
@@ -163,8 +167,9 @@ struct FleetDev {
   const FleetCold* cold;
   const struct FleetDev* self;  // device-resident copy of this block: the out-of-line rare paths read it from memory
   // ---- state ------------------------------------------------------------------------------------------
-  HotA* hot_a;        // [E,N]
-  HotB* hot_b;        // [E,N]
+  Hot* hot;           // [E,N]
+  double* soh;        // [E,N]
+  double* soc_deg;    // [E,N] (valid where the FROZEN bit is set)
   RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]

@@ -464,7 +464,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const TabX tx = d.tab[ti];
     const TabRec tb = tx.tb;
     const AuxRec ar = tx.ar;
-    const bool t090 = HOT_T090(d.hot_b[i].bits);  // target_soc survives reset (quirk Q7)
+    const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
     double soc = tb.sor;
@@ -474,15 +474,14 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    HotA ha;
-    ha.soc = soc;
-    ha.soc_deg = soc_deg;
-    HotB hb;
-    hb.soh = soh;
-    hb.hl = hl;
-    hb.bits = HOT_PACK(1, 0, 0, tb.there, t090);  // rainflow: the first sample is the first reversal point
-    d.hot_a[i] = ha;
-    d.hot_b[i] = hb;
+    const bool frozen = (soc_deg != soc);
+    Hot h;
+    h.soc = soc;
+    h.hl = hl;
+    h.bits = HOT_PACK(1, 0, 0, frozen, tb.there, t090);  // rainflow: the first sample is the first reversal point
+    d.hot[i] = h;
+    d.soh[i] = soh;
+    if (frozen) d.soc_deg[i] = soc_deg;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
       double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
       RfTop top;
@@ -535,7 +534,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py): what the first loads of a wavefront need -- its env record, its lanes' state records and action
     // -- is passed here once more, ahead of the argument block, so that those loads do not wait for an argument fetch.
-    EnvRec* __restrict__ p_env, const HotA* __restrict__ p_hot_a, const HotB* __restrict__ p_hot_b, const RfTop* __restrict__ p_rf_top,
+    EnvRec* __restrict__ p_env, const Hot* __restrict__ p_hot, const double* __restrict__ p_soh, const RfTop* __restrict__ p_rf_top,
     const void* __restrict__ p_actions, int p_E, int p_N,
     FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
@@ -558,15 +557,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   // env's time row, so they are requested before the env record is even read -- their latency then overlaps the
   // env record -> time row -> table record chain instead of following it.
   constexpr bool kEarly = !MULTI && !WIDE;
-  HotA ha_pre = {0.0, 0.0};
-  HotB hb_pre = {0.0, 0.0f, 0u};
+  Hot h_pre = {0.0, 0.0f, 0u};
+  double soh_pre = 0.0;
+  double deg_pre = 0.0;
   RfTop top_pre = {0.0, 0.0};
   float a32_pre = 0.0f;
   double a64_pre = 0.0;
   if (kEarly && g < N) {
     const size_t i0 = (size_t)e * N + g;
-    ha_pre = p_hot_a[i0];
-    hb_pre = p_hot_b[i0];
+    h_pre = p_hot[i0];
+    soh_pre = p_soh[i0];
+    deg_pre = d.soc_deg[i0];
     if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
     if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)p_actions)[i0];
     else a32_pre = ((const float*)p_actions)[i0];
@@ -677,13 +678,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
-      const HotA ha = kEarly ? ha_pre : d.hot_a[i];
-      const HotB hb = kEarly ? hb_pre : d.hot_b[i];
+      const Hot hb = kEarly ? h_pre : d.hot[i];
+      const double soh0 = kEarly ? soh_pre : d.soh[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
       const TabX tx1 = ld_tabx(tab_t1 + c);  // the only per-lane load that depends on the time row: requested first
       const TabRec tb1 = tx1.tb;
       const AuxRec ar = tx1.ar;
+      // last logged SOC sample: the SOC itself unless it was frozen when the EV left (see struct Hot)
+      // (requested unconditionally with the record itself: a load that depended on the record's FROZEN bit would add a
+      // memory round trip to the chain of the lanes whose EV is away)
+      const double deg_mem = kEarly ? deg_pre : d.soc_deg[i];
+      const double old_deg = HOT_FROZEN(hb.bits) ? deg_mem : hb.soc;
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -711,9 +717,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
-      double soc = ha.soc;
+      double soc = hb.soc;
       float hl = hb.hl;
-      const double cap = hb.soh * d.init_cap;
+      const double cap = soh0 * d.init_cap;
       bool t090 = HOT_T090(hb.bits);
       const double tgt = t090 ? 0.9 : d.target_soc;
       const bool present = (th == 1u);
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
       // departure :532, arrival :603, low state of health :615 are events too
-      if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (hb.soh <= 0.9);
+      if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (soh0 <= 0.9);
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
         const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
@@ -767,8 +773,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         hl = staying ? (float)((double)hl - d.dt) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
         soc = staying ? soc : tb1.sor;                       // `else: raise` is unreachable)
       }
-      if (hb.soh <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
-      const double old_deg = ha.soc_deg;
+      if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
 
       FLEET_STAMP(3);
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       int tail = HOT_TAIL(hb.bits), head = HOT_HEAD(hb.bits), sgn = HOT_SGN(hb.bits);
-      double soh = hb.soh;
+      double soh = soh0;
       if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
         // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes
         // the previous sample a reversal point
@@ -795,16 +800,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
 
       FLEET_STAMP(5);
-      if (env_ok) {  // whole 16-byte records, always: dense full-line stores
-        HotA na;
-        na.soc = soc;
-        na.soc_deg = soc_deg;
-        HotB nb;
-        nb.soh = soh;  // battery_cap = soh * init_cap is recomputed from soh on use (:673)
-        nb.hl = hl;
-        nb.bits = HOT_PACK(tail, head, sgn, tb1.there, t090);
-        st_rec16(d.hot_a + i, na);
-        st_rec16(d.hot_b + i, nb);
+      if (env_ok) {
+        // soc_deg == soc whenever the EV has hours left; otherwise it keeps its previous value, which has to be
+        // materialised the first time that happens (the EV just left) and stays where it is afterwards
+        const bool frozen = (hl == 0.0f);
+        if (frozen && !HOT_FROZEN(hb.bits)) d.soc_deg[i] = old_deg;
+        Hot nh;  // the whole 16-byte record, always: dense full-line stores
+        nh.soc = soc;
+        nh.hl = hl;
+        nh.bits = HOT_PACK(tail, head, sgn, frozen, tb1.there, t090);
+        st_rec16(d.hot + i, nh);
+        if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
         // the cached stack top only changes when a reversal point was pushed (then tail and/or head moved)
         if (DEG == FLEET_DEG_RAINFLOW && (tail != HOT_TAIL(hb.bits) || head != HOT_HEAD(hb.bits))) st_rec16(d.rf_top + i, top);
       }
@@ -864,11 +870,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 #endif
       for (int c = g; c < N; c += G) {
         const size_t i = (size_t)e * N + c;
-        HotB hb = d.hot_b[i];
-        const double sample = d.hot_a[i].soc_deg;
+        const Hot hb = d.hot[i];
+        const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
         const RfTop top = d.rf_top[i];
-        hb.soh = hb.soh - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err);
-        d.hot_b[i] = hb;
+        d.soh[i] = d.soh[i] - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err);
         if (!WIDE) break;
       }
     }
@@ -931,7 +936,7 @@ __global__ void fleet_dist_factor_kernel(FleetDev d, double* __restrict__ out) {
   const int e = (int)(i / d.N), c = (int)(i % d.N);
   const TabRec tb = d.tab[(size_t)d.env[e].h.t * d.N + c].tb;
   const double th = (double)tb.there;
-  const double tgt = HOT_T090(d.hot_b[i].bits) ? 0.9 : d.target_soc;
+  const double tgt = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc;
   const double cl = tgt * th - tb.sor;
   const double hn = cl * d.cold->batt_cap_nominal / d.cold->hn_denominator;
   out[i] = hn / ((double)tb.tl + 0.001);
@@ -946,11 +951,11 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
                        field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L || field == FLEET_F_LOG_ENERGY;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
-    case FLEET_F_SOC: ((double*)out)[i] = d.hot_a[i].soc; break;
-    case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot_b[i].hl; break;
-    case FLEET_F_SOH: ((double*)out)[i] = d.hot_b[i].soh; break;
-    case FLEET_F_SOC_DEG: ((double*)out)[i] = d.hot_a[i].soc_deg; break;
-    case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot_b[i].bits) ? 0.9 : d.target_soc; break;
+    case FLEET_F_SOC: ((double*)out)[i] = d.hot[i].soc; break;
+    case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot[i].hl; break;
+    case FLEET_F_SOH: ((double*)out)[i] = d.soh[i]; break;
+    case FLEET_F_SOC_DEG: ((double*)out)[i] = HOT_FROZEN(d.hot[i].bits) ? d.soc_deg[i] : d.hot[i].soc; break;
+    case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc; break;
     case FLEET_F_RF_LEN:
       ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfAcc*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;
       break;
@@ -987,7 +992,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-#define FLEET_PRE_ARGS d.env, d.hot_a, d.hot_b, d.rf_top, actions, d.E, d.N,  /* the preloaded leading arguments */
+#define FLEET_PRE_ARGS d.env, d.hot, d.soh, d.rf_top, actions, d.E, d.N,  /* the preloaded leading arguments */
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
