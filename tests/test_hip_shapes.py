@@ -40,7 +40,7 @@ def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=
     rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv, real_time=real_time))
     p = make_params(rc, tb, num_envs, seed=seed + 1)
     tf = time_features(tb)
-    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=4)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=min(32, max(4, num_envs // 64)))
     rng = np.random.default_rng(seed)
     np.testing.assert_array_equal(hip.reset(), cpu.reset())
     np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))  # same Philox start rows
@@ -151,3 +151,19 @@ def test_real_time_event_skipping_matches_oracle(uc, n_evs, num_envs, deg, norm)
     """real_time=True: one launch repeats the step with the same action until a relevant event (fleet_environment.py:453,
     692-699); envs advance by different numbers of rows per step."""
     _compare(uc, n_evs, num_envs, deg, norm, steps=260 if n_evs < 100 else 150, seed=11, real_time=True)
+
+
+def test_headline_size_full_batch():
+    """BASELINE.json configs[2] at its FULL size -- 4096 envs x 50 EVs, caretaker fleet, load+pv, rainflow -- HIP against the
+    oracle over more than one 24 h episode (the oracle runs OpenMP over envs; a few seconds on the GPU box's host)."""
+    _compare("ct", 50, 4096, "rainflow", False, steps=200, seed=21)
+
+
+def test_c5_shard_size_full_batch():
+    """BASELINE.json configs[4], one GPU's shard at FULL size: 8192 envs x 200 EVs (several EVs per lane), rainflow."""
+    _compare("lmd", 200, 8192, "rainflow", False, steps=100, seed=22)
+
+
+def test_c4_shard_size_full_batch():
+    """BASELINE.json configs[3], one GPU's shard at full size: 2048 envs x 50 EVs, utility fleet, normalised observations."""
+    _compare("ut", 50, 2048, "rainflow", True, steps=200, seed=23)
