@@ -1,6 +1,6 @@
 """fleetrl_amd -- MI355X-native batched FleetRL `FleetEnv.step()` hot path.
 
-    from fleetrl_amd import FleetEnv, FleetVecEnv, FleetVectorEnv
+    from fleetrl_amd import FleetEnv, FleetVecEnv, FleetVectorEnv, FleetMixedVecEnv
 """
 __version__ = "0.1.0"
 
@@ -10,6 +10,10 @@ def __getattr__(name):  # lazy: importing the package must not require the HIP l
         from . import vec_env
 
         return getattr(vec_env, name)
+    if name == "FleetMixedVecEnv":
+        from . import mixed
+
+        return mixed.FleetMixedVecEnv
     if name in ("FleetBatch", "FleetHipError"):
         from . import batch
 

@@ -148,3 +148,48 @@ def test_data_log_matches_the_reference_logger():
             np.testing.assert_allclose(np.asarray(lg["Action"].iloc[k], dtype=np.float64), g.log_action[e, k])
     assert (g.log_grid > 0).any() and (g.log_socv > 0).any() and (np.abs(g.log_deg) > 0).any()
     venv.close()
+
+
+def test_mixed_fleet_vec_env_equals_its_groups_stepped_separately():
+    """BASELINE.json's largest configuration mixes fleet types: three groups (lmd / ct / ut tables and parameters) behind one
+    vector env, every group a handle with its own stream writing into slices of shared device buffers.  Must equal the
+    same three groups stepped as separate FleetVecEnvs (same env-id offsets = same start-row streams)."""
+    from fleetrl_amd import FleetMixedVecEnv, FleetVecEnv
+    from fleetrl_amd.synth import synth_tables
+    from test_hip_shapes import _cfg
+
+    N = 12
+    specs = [("lmd", 9), ("ct", 17), ("ut", 6)]
+    groups = [(_cfg(uc, "rainflow", False), n, dict(tables=synth_tables(uc, N, seed=40 + k), seed=3)) for k, (uc, n) in enumerate(specs)]
+    mixed = FleetMixedVecEnv(groups)
+    assert mixed.num_envs == 32 and mixed.action_space.shape == (N,)
+    singles, off = [], 0
+    for cfg, n, kw in groups:
+        singles.append(FleetVecEnv(cfg, n, env_id_offset=off, **kw))
+        off += n
+    obs = mixed.reset()
+    np.testing.assert_array_equal(obs, np.concatenate([s.reset() for s in singles]))
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for k in range(110):  # 24 h episodes: one auto-reset per env
+        a = rng.uniform(-1, 1, size=(32, N)).astype(np.float32)
+        o, r, d, infos = mixed.step(a)
+        parts, lo = [], 0
+        for s in singles:
+            parts.append(s.step(a[lo:lo + s.num_envs]))
+            lo += s.num_envs
+        np.testing.assert_array_equal(o, np.concatenate([p[0] for p in parts]))
+        np.testing.assert_array_equal(r, np.concatenate([p[1] for p in parts]))
+        np.testing.assert_array_equal(d, np.concatenate([p[2] for p in parts]))
+        want_infos = [x for p in parts for x in p[3]]
+        for got, want in zip(infos, want_infos):
+            assert set(got) == set(want)
+            if "terminal_observation" in want:
+                np.testing.assert_array_equal(got["terminal_observation"], want["terminal_observation"])
+                assert got["episode"] == want["episode"]
+                n_done += 1
+    assert n_done == 32
+    assert len(mixed.env_method("get_time")) == 32 and mixed.env_method("is_done", indices=[0, 31]) == [False, False]
+    mixed.close()
+    for s in singles:
+        s.close()
