@@ -29,7 +29,7 @@
 #include "fleet_device.h"
 
 #ifdef FLEET_STAMPS
-// Diagnostic build only (tools/stamps.sh): s_memtime stamps of wave 0 of every workgroup at fixed points of the step,
+// Diagnostic build only (tools/stamps.py): s_memtime stamps of wave 0 of every workgroup at fixed points of the step,
 // written to a buffer nothing else reads.  Never compiled into the product library.
 __device__ unsigned long long fleet_stamp_buf[4096 * 16];
 #define FLEET_STAMP(k)                                                                                   \
@@ -49,11 +49,16 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
+// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The
+// single-step kernel needs 97 VGPRs; the multi-step kernel 124-126, i.e. it also runs 4 waves per SIMD although it is only
+// asked for 2 (asking for 3 or 4 makes the register allocator spill a little and is slower).
+// Other FLEET_* macros in this file (FLEET_ABL_*, FLEET_NT_*, FLEET_STAMPS, FLEET_OBS_EVERY_STEP) are diagnostics for
+// tools/ab_build.sh and never defined in the product build.
 #ifndef FLEET_SINGLE_WAVES
-#define FLEET_SINGLE_WAVES 4  // same for the single-step kernel
+#define FLEET_SINGLE_WAVES 4
 #endif
 #ifndef FLEET_MULTI_WAVES
-#define FLEET_MULTI_WAVES 2  // waves per SIMD the multi-step kernel is compiled for (register budget 512 / this)
+#define FLEET_MULTI_WAVES 2
 #endif
 #ifndef FLEET_KBLOCK
 #define FLEET_KBLOCK 256
