@@ -129,6 +129,15 @@ def load_library():
         return _LIB
     path = lib_path()
     if not os.path.isfile(path):
+        # not built yet (fresh checkout): compile it now if the ROCm toolchain is here -- still the HIP library, never a
+        # substitute for it
+        try:
+            from . import build as _build
+
+            _build.build()
+        except Exception:  # no hipcc / compile error: report the missing library below
+            pass
+    if not os.path.isfile(path):
         raise FleetHipError(ERR_NODEVICE, f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     # One HIP runtime per process: PyTorch bundles its own libamdhip64 and only finds the GPU if that copy is the one
