@@ -153,3 +153,50 @@ def test_get_dev_matches_get():
         hip.synchronize()
         np.testing.assert_array_equal(buf.cpu().numpy(), hip.get(name))
     assert hip.get("last_ep_len").min() == g.ep_steps
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/capi_demo.c: the library driven from a plain C program (no Python / PyTorch in that process), against the
+    same run through the Python front end."""
+    import os
+    import subprocess
+
+    from fleetrl_amd import build
+    from fleetrl_amd.batch import FleetBatch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(build.lib_path())
+    exe = str(tmp_path / "capi_demo")
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "capi_demo.c"), "-o", exe,
+                    "-L", lib_dir, "-l:libfleet_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
+    g = load_trace("ct5_both_rainflow")
+    E, steps = 11, 230
+    p = params_for(g, num_envs=E)
+    p.picker_mode = _capi.PICK_RANDOM
+    p.start_lo, p.start_hi = 0, g.tables.T - g.ep_steps - 60
+    tb = g.tables
+    (tmp_path / "params.bin").write_bytes(bytes(p))
+    cols = [tb.there.astype(np.uint8), tb.time_left.astype(np.float32), tb.soc_on_return.astype(np.float64)] + \
+           [np.asarray(getattr(tb, k), dtype=np.float64) for k in ("delu", "tariff", "prc", "trc", "load", "pv")] + \
+           [np.asarray(getattr(tb, k), dtype=np.uint8) for k in ("hour", "minute", "month", "weekday")]
+    (tmp_path / "tables.bin").write_bytes(b"".join(np.ascontiguousarray(c).tobytes() for c in cols))
+    out = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "tables.bin"), str(steps)], check=True,
+                         capture_output=True, text=True).stdout.split()
+    c_reward, c_episodes, c_soc, c_dim = float(out[0]), int(out[1]), float(out[2]), int(out[3])
+
+    hip = FleetBatch(p, tb, None)  # time features computed by the library, as in the C program
+    hip.reset()
+    reward_sum, episodes = 0.0, 0
+    idx = np.arange(E * g.N, dtype=np.int64)
+    for s in range(steps):
+        a = (((idx * 7 + s * 13) % 21 - 8) / 12.0).astype(np.float32).reshape(E, g.N)
+        _o, r, d, _t = hip.step(a)
+        for e in range(E):
+            reward_sum += float(r[e])
+        episodes += int(d.sum())
+    assert c_dim == hip.obs_dim and c_episodes == episodes and episodes >= E
+    assert c_reward == reward_sum
+    soc_sum = 0.0
+    for v in hip.get("soc").reshape(-1).tolist():  # same left-to-right float64 sum as the C loop
+        soc_sum += v
+    assert c_soc == soc_sum
