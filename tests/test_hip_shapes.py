@@ -167,3 +167,40 @@ def test_c5_shard_size_full_batch():
 def test_c4_shard_size_full_batch():
     """BASELINE.json configs[3], one GPU's shard at full size: 2048 envs x 50 EVs, utility fleet, normalised observations."""
     _compare("ut", 50, 2048, "rainflow", True, steps=200, seed=23)
+
+
+def test_sharding_invariance_and_determinism():
+    """Size-independent properties at the headline geometry: (1) a batch of 2E envs equals two batches of E envs with
+    env_id_offset 0 and E (what the multi-GPU layout relies on: start-row streams are keyed by the global env id);
+    (2) two identical runs are bit-identical (no atomics / order-dependent sums on the path)."""
+    from fleetrl_amd.batch import FleetBatch
+
+    tb = _tables("ct", 50)
+    rc = resolve_config(_cfg("ct", "rainflow", False))
+    tf = time_features(tb)
+    E = 96
+    whole = FleetBatch(make_params(rc, tb, 2 * E, seed=5), tb, tf)
+    again = FleetBatch(make_params(rc, tb, 2 * E, seed=5), tb, tf)
+    lo = FleetBatch(make_params(rc, tb, E, seed=5, env_id_offset=0), tb, tf)
+    hi = FleetBatch(make_params(rc, tb, E, seed=5, env_id_offset=E), tb, tf)
+    o = whole.reset()
+    np.testing.assert_array_equal(o, again.reset())
+    np.testing.assert_array_equal(o, np.concatenate([lo.reset(), hi.reset()]))
+    rng = np.random.default_rng(9)
+    for s in range(130):
+        a = rng.uniform(-1, 1, size=(2 * E, 50)).astype(np.float32)
+        ow, rw, dw, tw = whole.step(a)
+        oa, ra, da, ta = again.step(a)
+        ol, rl, dl, tl = lo.step(a[:E])
+        oh, rh, dh, th = hi.step(a[E:])
+        for x, y in ((ow, oa), (rw, ra), (dw, da)):
+            np.testing.assert_array_equal(x, y, err_msg=f"run-to-run, step {s}")
+        np.testing.assert_array_equal(ow, np.concatenate([ol, oh]), err_msg=f"sharded obs, step {s}")
+        np.testing.assert_array_equal(rw, np.concatenate([rl, rh]))
+        np.testing.assert_array_equal(dw, np.concatenate([dl, dh]))
+    for name in ("soc", "soh", "fd_cyc", "rf_len", "time_idx", "last_ep_return"):
+        np.testing.assert_array_equal(whole.get(name), np.concatenate([lo.get(name), hi.get(name)]), err_msg=name)
+        np.testing.assert_array_equal(whole.get(name), again.get(name), err_msg=name)
+    assert whole.get("episodes").min() >= 1
+    for b in (whole, again, lo, hi):
+        b.close()
