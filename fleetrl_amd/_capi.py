@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -77,6 +77,9 @@ _TABLE_FIELDS = (
     ("trc", C.POINTER(C.c_double)), ("load", C.POINTER(C.c_double)), ("pv", C.POINTER(C.c_double)),
     ("hour", C.POINTER(C.c_uint8)), ("minute", C.POINTER(C.c_uint8)), ("month", C.POINTER(C.c_uint8)),
     ("weekday", C.POINTER(C.c_uint8)), ("time_feat", C.POINTER(C.c_float)),
+    # irregular time grids (real_time), all NULL / 0 otherwise
+    ("dt_row", C.POINTER(C.c_double)), ("finish_row", C.POINTER(C.c_int32)), ("lookahead_row", C.POINTER(C.c_int32)),
+    ("lookahead_cols", C.c_int32), ("reserved0", C.c_int32), ("second", C.POINTER(C.c_uint8)),
 )
 
 
@@ -105,6 +108,13 @@ def pack_tables(tables, time_feat: np.ndarray | None):
         t.time_feat = ptr(time_feat, np.float32, C.c_float)
     else:
         t.time_feat = C.POINTER(C.c_float)()
+    irr = getattr(tables, "meta", {}).get("irregular")
+    if irr is not None:  # attached by fleetrl_amd.params.make_params for a real_time config on an irregular grid
+        t.dt_row = ptr(irr["dt_row"], np.float64, C.c_double)
+        t.finish_row = ptr(irr["finish_row"], np.int32, C.c_int32)
+        t.lookahead_row = ptr(irr["lookahead_row"], np.int32, C.c_int32)
+        t.lookahead_cols = int(irr["lookahead_row"].shape[1])
+        t.second = ptr(irr["second"], np.uint8, C.c_uint8)
     return t, keep
 
 

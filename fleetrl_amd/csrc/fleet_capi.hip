@@ -105,6 +105,11 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
   if (p->normalize && p->include_pv && !p->include_building)
     return "normalize with pv but without building load crashes in the reference (quirk Q4); unsupported";
+  if ((t->dt_row != nullptr) != (t->finish_row != nullptr) || (t->dt_row && (!t->lookahead_row || t->lookahead_cols < 1)))
+    return "irregular-grid tables must be given together (dt_row, finish_row, lookahead_row)";
+  if (t->dt_row && !p->real_time) return "an irregular time grid needs real_time = 1";
+  if (t->lookahead_row && (t->lookahead_cols < p->price_lookahead || t->lookahead_cols < p->bl_pv_lookahead))
+    return "lookahead_cols smaller than a look-ahead";
   if (p->real_time && p->log_data) return "log_data is not available with real_time (only the last skipped row would be logged)";
   if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > p->table_rows - 1) return "start range outside the table";
   if (!t->there || !t->time_left || !t->soc_on_return || !t->delu || !t->tariff || !t->prc || !t->trc || !t->load ||
@@ -115,8 +120,12 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
 
 // hourly look-ahead row: `resample("H").first()` of the slice starting at t (observer_bl_pv.py:50-80):
 // bucket 0 = row t, bucket k>=1 = first row of clock hour floor_hour(t)+k.
-inline int lookahead_row(const FleetParams& p, int t, int k) {
+inline int lookahead_row(const FleetParams& p, const FleetTables& tb, int t, int k) {
   if (k == 0) return t;
+  if (tb.lookahead_row) {  // irregular grid: tabulated by date on the host
+    const int r = tb.lookahead_row[(size_t)t * tb.lookahead_cols + (k - 1)];
+    return r < 0 ? p.table_rows - 1 : r;
+  }
   int r = ((t + p.hour_phase) / p.steps_per_hour + k) * p.steps_per_hour - p.hour_phase;
   return r > p.table_rows - 1 ? p.table_rows - 1 : r;
 }
@@ -134,12 +143,12 @@ void build_tail_rows(const FleetParams& p, const FleetTables& t, int tail_a, int
     float* o = out.data() + (size_t)r * stride;
     int k0 = 0;
     for (int k = 0; k <= L; ++k) {
-      double v = (t.delu[lookahead_row(p, r, k)] + p.fixed_markup) * p.variable_multiplier;
+      double v = (t.delu[lookahead_row(p, t, r, k)] + p.fixed_markup) * p.variable_multiplier;
       if (norm) v = (v - p.min_price) / (p.max_price - p.min_price);
       o[k0++] = (float)v;
     }
     for (int k = 0; k <= L; ++k) {
-      double v = t.tariff[lookahead_row(p, r, k)] * (1 - p.feed_in_deduction);
+      double v = t.tariff[lookahead_row(p, t, r, k)] * (1 - p.feed_in_deduction);
       if (norm) v = (v - p.min_tariff) / (p.max_tariff - p.min_tariff);
       o[k0++] = (float)v;
     }
@@ -147,7 +156,7 @@ void build_tail_rows(const FleetParams& p, const FleetTables& t, int tail_a, int
     if (p.include_building) {
       load0 = t.load[r];
       for (int k = 0; k <= B; ++k) {
-        double v = t.load[lookahead_row(p, r, k)];
+        double v = t.load[lookahead_row(p, t, r, k)];
         if (norm) v = v / p.max_building;
         o[k0++] = (float)v;
       }
@@ -155,7 +164,7 @@ void build_tail_rows(const FleetParams& p, const FleetTables& t, int tail_a, int
     if (p.include_pv) {
       pv0 = t.pv[r];
       for (int k = 0; k <= B; ++k) {
-        double v = t.pv[lookahead_row(p, r, k)];
+        double v = t.pv[lookahead_row(p, t, r, k)];
         if (norm) v = v / p.max_pv;
         o[k0++] = (float)v;
       }
@@ -205,9 +214,10 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
     long connected = 0;
     for (int c = 0; c < N; ++c) connected += t.there[(size_t)r * N + c];
     if (connected < 1) connected = 1;
-    const double pv_energy = p.include_pv ? t.pv[r] * p.dt : 0.0;
+    const double pv_energy = p.include_pv ? t.pv[r] * (t.dt_row ? t.dt_row[r] : p.dt) : 0.0;
     q.pv_share = pv_energy / (double)connected;
     q.pad = 0;
+    q.dt = t.dt_row ? t.dt_row[r] : p.dt;
     uint8_t f = 0;
     if (t.hour[r] == 14 && t.minute[r] == 45) f |= FLEET_TFLAG_DEG;
     if (t.hour[r] > 11 && t.hour[r] < 15) f |= FLEET_TFLAG_LUNCH;
@@ -312,13 +322,18 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   {
     // night-charging policy (benchmarking/night_charging.py:81-98): clock of every table row + per-env window state
     std::vector<uint16_t> hm((size_t)T);
-    for (int i = 0; i < T; ++i) hm[i] = (uint16_t)((t->hour[i] << 8) | t->minute[i]);
+    for (int i = 0; i < T; ++i)
+      hm[i] = (uint16_t)((t->hour[i] << 8) | t->minute[i] | ((t->second && t->second[i]) ? 0x8000 : 0));  // bit 15: off the minute
     if ((rc = dev_upload(b, &cd.tab_hm, hm.data(), hm.size()))) return rc;
     std::vector<int32_t> idle((size_t)E, FLEET_NIGHT_IDLE);
     if ((rc = dev_alloc(b, &cd.night_start, (size_t)E, false))) return rc;
     HIP_TRY(b, hipMemcpyAsync(cd.night_start, idle.data(), idle.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     cd.night_hour = -1; cd.night_minute = 0; cd.night_limit_s = 0;
     cd.step_s = (int)std::llround(p->dt * 3600.0);
+    HIP_TRY(b, hipStreamSynchronize(b->stream));
+  }
+  if (t->finish_row) {  // irregular time grid (real_time): episode-end row by date (the per-row step length is in PhysRow)
+    if ((rc = dev_upload(b, &d.tab_finish, t->finish_row, (size_t)T))) return rc;
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
   if ((rc = dev_alloc(b, &b->cold_dev, 1))) return rc;

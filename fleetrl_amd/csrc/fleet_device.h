@@ -17,7 +17,7 @@
 #include "../../include/fleet_hip.h"
 
 // ---- read-only tables ---------------------------------------------------------------------------------------
-// Physics row of time row t (64 B): per-time scalars pre-combined on the host (fleet_capi.hip build_phys_rows()).
+// Physics row of time row t (72 B): per-time scalars pre-combined on the host (fleet_capi.hip build_phys_rows()).
 // k_charge / k_discharge / pv_share use exactly the reference's float64 operations (bit-identical); k_cost / k_rev
 // re-associate two multiplications of the money terms (cashflow differs from the reference by <= 1 ulp per EV).
 struct PhysRow {
@@ -30,6 +30,8 @@ struct PhysRow {
   double pv_share;      // pv[t]*dt / max(sum(There[t]),1)                              (ev_charger.py:134-142)
   uint32_t flags_next;  // FLEET_TFLAG_* of time row t+1 (the row the step advances to)
   uint32_t pad;
+  double dt;            // hours from row t to row t+1: `get_next_dt` (fleet_environment.py:455, :994-1008); the model's
+                        // constant step on a regular grid, per row on an irregular one (real_time)
 };
 
 // Table record of (time row t, EV c), 16 B.
@@ -164,6 +166,7 @@ struct FleetDev {
   const PhysRow* tab_phys;    // [T]
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]
+  const int32_t* tab_finish;  // [T] episode-end row of an episode starting on row t (-1: never), or nullptr (t + episode_steps)
   const FleetCold* cold;
   const struct FleetDev* self;  // device-resident copy of this block: the out-of-line rare paths read it from memory
   // ---- state ------------------------------------------------------------------------------------------

@@ -353,7 +353,8 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
 // `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, const RfTop& top, uint32_t& err) {
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, const RfTop& top, uint32_t& err,
+                                             double dt_hours) {
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
   const double* stk = row + 4;
   const FleetCold* cd = d.cold;
@@ -363,7 +364,6 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
   const int L = acc.rf_len;
   const int nc = acc.nc;
   const double mean_sum0 = acc.mean_sum, csum0 = acc.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
-  const double dt_hours = cd->dt;
   const double st = d.stress_temp;
 
   int nv = 0;
@@ -439,14 +439,14 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
 
 // EmpiricalDegradation.calculate_degradation for one EV (empirical_degradation.py:29-99; quirks Q1, Q5):
 // the last two log entries are the SOC sample before and after this step.
-__device__ __forceinline__ double linear_degradation(const FleetDev& d, double old_soc, double new_soc) {
+__device__ __forceinline__ double linear_degradation(const FleetDev& d, double old_soc, double new_soc, double dt_hours) {
   const double avg = (old_soc + new_soc) / 2.0;
   // nearest of {0, 40, 90} to a SOC on a [0,1] scale -- replicated literally (argmin, first wins ties)
   int best = 0;
   double bd = fabs(0.0 - avg);
   if (fabs(40.0 - avg) < bd) { best = 1; bd = fabs(40.0 - avg); }
   if (fabs(90.0 - avg) < bd) best = 2;
-  const double cal = (best == 0 ? 0.0065 : best == 1 ? 0.0293 : 0.065) * d.dt / 8760.0;
+  const double cal = (best == 0 ? 0.0065 : best == 1 ? 0.0293 : 0.065) * dt_hours / 8760.0;
   const double dod = fabs(new_soc - old_soc);
   const double cyc = (d.evse_power <= 22.0) ? dod * 0.000125 / 2.0 : dod * 0.000167 / 2.0;
   return cal + cyc;
@@ -462,7 +462,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   const FleetCold* cd = d.cold;
   const int start = choose_start(cd, d.E, e, r.episodes);
   r.t = start;
-  r.t_end = start + d.episode_steps;
+  r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
   r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
@@ -637,6 +637,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
     // (not in rainflow mode, where vector registers are the scarcer resource)
     const PhysRow ph = d.tab_phys[t + (DEG == FLEET_DEG_RAINFLOW ? 0 : vzero)];
+    // hours this step spans: `get_next_dt` (:455, :994-1008) -- a constant unless the grid is irregular (real_time only)
+    const double dt_step = ph.dt;
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // merged with selects / min / max, so a wavefront whose lanes hold both signs (the normal case) does not walk two
       // masked branches, and there is no exec-mask bookkeeping on the hot path.
       const bool pos = (a >= 0.0);
-      const double dem = d.p_avail * a * d.dt;   // demanded (dis)charge energy :101 / :162
+      const double dem = d.p_avail * a * dt_step;   // demanded (dis)charge energy :101 / :162
       const double need = (tgt - soc) * cap;     // ev_total_energy_demand :100
       const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
       // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
       {
         const bool staying = (ntl != 0.0f) && (hl != 0.0f);  // still charging :593-594; otherwise no car in the next
-        hl = staying ? (float)((double)hl - d.dt) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
+        hl = staying ? (float)((double)hl - dt_step) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
         soc = staying ? soc : tb1.sor;                       // `else: raise` is unreachable)
       }
       if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
           sgn = s_next;
         }
       }
-      if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg);
+      if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
 
       FLEET_STAMP(5);
       if (env_ok) {
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         const Hot hb = d.hot[i];
         const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
         const RfTop top = d.rf_top[i];
-        d.soh[i] = d.soh[i] - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err);
+        d.soh[i] = d.soh[i] - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
         if (!WIDE) break;
       }
     }
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
           reset_env<G>(*d.self, e, g, leader, r, obs_row);
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
-          r.t_end = r.t + d.episode_steps;
+          r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;
           r.nsamp = (DEG != FLEET_DEG_NONE) ? 1 : 0;
         }
         ep_return = 0.0;
@@ -912,7 +914,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // EventManager.check_event (event_manager.py:16-31): the advanced row's clock minute == 15 is an event of its own;
       // the end of the episode is one (:629); running off the table ends the loop (the reference would raise there)
       last_done = is_done;
-      const bool minute15 = (d.cold->tab_hm[t1] & 255) == 15;
+      const int hm1 = d.cold->tab_hm[t1];
+      const bool minute15 = ((hm1 & 255) == 15) && !(hm1 & 0x8000);  // minute == 15 and second == 0
       if (group_any<G>(ev_lane) || is_done || minute15 || (t + 1 > d.T - 1)) break;
     }
   }

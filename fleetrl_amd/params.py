@@ -64,6 +64,32 @@ def validate_supported(rc: ResolvedConfig) -> None:
         raise ValueError("minutes per step must divide 60")
 
 
+def irregular_grid_tables(tables: FleetTables, rc: ResolvedConfig) -> dict:
+    """What the step needs on an irregular time grid (real_time only), as row-indexed tables:
+    dt_row      hours to the next row -- `get_next_dt` (fleet_environment.py:994-1008): (date[t+1] - date[t]).total_seconds()/3600
+    finish_row  the row whose date equals date[t] + episode_length hours (`finish_time`, :355; the done test is an exact
+                date comparison, :627), -1 if there is none
+    lookahead_row[t, k-1]  first row of clock hour floor_hour(date[t]) + k (`resample("H", on="date").first()` of the slice
+                starting at t, observer_bl_pv.py:53-79), -1 past the end of the table
+    second      seconds of the clock time (EventManager.check_event wants minute == 15 and second == 0)."""
+    d = tables.dates.astype("datetime64[s]").astype(np.int64)
+    T = d.size
+    dt = np.empty(T)
+    dt[:-1] = (d[1:] - d[:-1]) / 3600.0
+    dt[-1] = dt[-2] if T > 1 else rc.dt
+    want = d + rc.episode_length * 3600
+    k = np.searchsorted(d, want)
+    finish = np.where((k < T) & (d[np.clip(k, 0, T - 1)] == want), k, -1).astype(np.int32)
+    cols = max(rc.price_lookahead, rc.bl_pv_lookahead, 1)
+    hour0 = (d // 3600) * 3600
+    look = np.empty((T, cols), dtype=np.int32)
+    for j in range(1, cols + 1):
+        r = np.searchsorted(d, hour0 + j * 3600)  # first row at or after the top of that hour ...
+        ok = (r < T) & (d[np.clip(r, 0, T - 1)] < hour0 + (j + 1) * 3600)  # ... that still lies inside it
+        look[:, j - 1] = np.where(ok, r, -1)
+    return dict(dt_row=dt, finish_row=finish, lookahead_row=look, second=(d % 60).astype(np.uint8))
+
+
 def time_features(tables: FleetTables) -> np.ndarray:
     """[T,6] float32: month/week/hour sin,cos exactly as the observers compute them
     (observer_bl_pv.py:100-107: `np.sin(2 * np.pi * time.month/12)` ... on Python scalars, then the
@@ -160,13 +186,17 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     p.auto_reset = int(auto_reset)
     p.env_id_offset = int(env_id_offset)
     p.log_data = int(bool(rc.raw.get("log_data", False)))
-    if rc.real_time:
-        # event-skipping needs a regular grid here: the reference's per-row dt (`get_next_dt`, :994-1008) is tabulated
-        # as one constant, and the hourly look-ahead blocks are indexed arithmetically
-        step = np.diff(tables.dates.astype("datetime64[s]").astype(np.int64))
-        if step.size and not np.all(step == rc.minutes * 60):
-            raise ValueError("real_time=True on an irregular time grid is not supported (rows must be "
-                             f"{rc.minutes} min apart); resample the schedule first")
+    step = np.diff(tables.dates.astype("datetime64[s]").astype(np.int64))
+    if step.size and not np.all(step == rc.minutes * 60):
+        if not rc.real_time:
+            raise ValueError(f"table rows must be {rc.minutes} min apart unless real_time=True (the reference resamples "
+                             "the schedule to the model frequency otherwise, data_processing.py:54-62)")
+        if not (rc.include_building and rc.include_pv):
+            raise ValueError("an irregular time grid only runs with include_building and include_pv in the reference (the "
+                             "other observers look the window end up by exact date, observer_price_only.py:51); unsupported")
+        tables.meta["irregular"] = irregular_grid_tables(tables, rc)
+    else:
+        tables.meta.pop("irregular", None)
     p.real_time = int(rc.real_time)
     s = rc.seed if seed is None else seed
     p.seed = int(s) if s is not None else 0

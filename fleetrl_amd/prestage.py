@@ -374,15 +374,22 @@ def build_tables(
     fixed_markup: float,
     variable_multiplier: float,
     feed_in_deduction: float,
+    real_time: bool = False,
 ) -> FleetTables:
-    """Assemble every table from parsed inputs.  `spot`/`tariff`/`load`/`pv` are (dates, values) pairs."""
-    schedule = _resample_regular(schedule, minutes)
+    """Assemble every table from parsed inputs.  `spot`/`tariff`/`load`/`pv` are (dates, values) pairs.
+    `real_time`: the schedule is used as it is, without resampling to the model frequency, and its own dates are the
+    grid (data_processing.py:54-62, 73-82) -- the rows may then be irregularly spaced."""
+    if not real_time:
+        schedule = _resample_regular(schedule, minutes)
     dates, there, tl, sor, cons = schedule_tables(schedule, minutes, target_soc, init_battery_cap)
     T = dates.size
-    # model grid: date_range(min, max, freq) (data_processing.py:76-79) == the per-car dates for regular data
-    grid = dates[0] + np.arange(T) * np.timedelta64(minutes * 60, "s")
-    if not np.array_equal(grid, dates):
-        raise ValueError("schedule dates are not a regular grid")
+    if real_time:
+        grid = dates  # date_range = schedule["date"].unique() (:81-82)
+    else:
+        # model grid: date_range(min, max, freq) (data_processing.py:76-79) == the per-car dates for regular data
+        grid = dates[0] + np.arange(T) * np.timedelta64(minutes * 60, "s")
+        if not np.array_equal(grid, dates):
+            raise ValueError("schedule dates are not a regular grid")
 
     delu = upsample_backward(grid, *spot)
     trf = upsample_backward(grid, *tariff)
@@ -458,4 +465,5 @@ def build_tables_from_config(cfg: dict, schedule: Schedule | None = None) -> Fle
         fixed_markup=rc.fixed_markup,
         variable_multiplier=rc.variable_multiplier,
         feed_in_deduction=rc.feed_in_deduction,
+        real_time=rc.real_time,
     )

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 2
+#define FLEET_ABI_VERSION 3
 
 /* status codes */
 #define FLEET_OK 0
@@ -96,7 +96,7 @@ typedef struct FleetParams {
                                FLEET_F_LOG_*; 0: skip them */
   int32_t real_time;        /* 1: event-skipping step (fleet_environment.py:453,692-699, event_manager.py:16-31): the same
                                action is applied row after row until a relevant event (departure, arrival, penalty,
-                               overload, episode end, clock minute 15); regular time grids only */
+                               overload, episode end, clock minute 15); irregular time grids need FleetTables.dt_row etc. */
   int32_t reserved0;
   uint64_t seed;            /* Philox key for the random/eval picker */
 
@@ -153,6 +153,18 @@ typedef struct FleetTables {
   const uint8_t* month;         /* [T]  1..12                                  */
   const uint8_t* weekday;       /* [T]  Monday = 0                             */
   const float* time_feat;       /* [T,6] month/week/hour sin,cos as float32, or NULL (library computes with libm) */
+  /* Irregular time grids (real_time only; all NULL / 0 for a regular grid, where the library derives them from
+   * FleetParams.dt / steps_per_hour / hour_phase).  The reference reads the step length off the data
+   * (`get_next_dt`, fleet_environment.py:994-1022), ends the episode on the row whose date equals start + episode_length
+   * (:355, :627) and takes the hourly look-ahead values from the first row of each clock hour
+   * (`resample("H").first()`, observer_bl_pv.py:53-79). */
+  const double* dt_row;         /* [T]  hours from row t to row t+1 (last row: any positive value)                   */
+  const int32_t* finish_row;    /* [T]  row whose date is date[t] + episode_length hours, or -1 (the episode never ends) */
+  const int32_t* lookahead_row; /* [T,lookahead_cols]  column k-1: first row of clock hour floor_hour(date[t]) + k, k >= 1;
+                                   -1: no such row                                                                     */
+  int32_t lookahead_cols;       /* >= max(price_lookahead, bl_pv_lookahead)                                           */
+  int32_t reserved0;
+  const uint8_t* second;        /* [T]  seconds of the row's clock time (the clock-minute-15 event needs second == 0) */
 } FleetTables;
 
 typedef struct FleetEnvBatch* fleet_handle;

@@ -259,6 +259,11 @@ RT_CONFIGS = {
                                deg_emp=True, episode_length=24, real_time=True), 3, 2, 2),
     "ut2_both_norm_nodeg": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
                                  normalize_in_env=True, calculate_degradation=False, episode_length=24, real_time=True), 2, 2, 2),
+    # the reference's own irregular example: inputs/test_lmd.csv has rows at 00:00, 00:07, 00:15, then every 15 min (per-row dt,
+    # fleet_environment.py:994-1022).  Only the load+pv observer runs on it (the others look the window end up by exact date).
+    # n_evs = 0: the shipped single-EV file; the first episode of env 0 starts on row 0 and walks the irregular rows.
+    "lmd1_both_irregular": (dict(use_case="lmd", schedule_name="test_lmd.csv", building_name="load_lmd.csv", include_building=True,
+                                 include_pv=True, calculate_degradation=True, deg_emp=True, episode_length=24, real_time=True), 0, 2, 2),
 }
 
 
@@ -279,8 +284,9 @@ def run_config_rt(name: str):
 
     ov, n_evs, E, episodes = RT_CONFIGS[name]
     ov = dict(ov)
-    dp, sched = stacked_inputs_dir(ov["use_case"], n_evs)
-    ov.update(data_path=dp, schedule_name=sched)
+    if n_evs:
+        dp, sched = stacked_inputs_dir(ov["use_case"], n_evs)
+        ov.update(data_path=dp, schedule_name=sched)
     ov.setdefault("target_soc", 0.85)
     rng = np.random.default_rng(sum(map(ord, "rt_" + name)))
     ep_rows = ov["episode_length"] * 4
@@ -311,8 +317,10 @@ def run_config_rt(name: str):
         acts = make_actions_rt(rng, cap, N)
         rec["actions"][e] = acts
         if e == 0:
-            span0 = int(rng.integers(0, T - 1 - 60 * 96 - 20 * 96))
+            span0 = 0 if name.endswith("irregular") else int(rng.integers(0, T - 1 - 60 * 96 - 20 * 96))
         starts[:, e] = rng.integers(span0, span0 + 20 * 96, size=episodes)
+        if name.endswith("irregular") and e == 0:
+            starts[0, 0] = 0
         k = 0
         for ep in range(episodes):
             set_static_start(env, int(starts[ep, e]))
