@@ -58,3 +58,23 @@ def test_kahan_group_sum_matches_sequential_compensated_sum():
             c = t - s - y
             s = t
         assert got[gidx] == s
+
+
+@pytest.mark.reference
+def test_prestage_real_time_keeps_the_irregular_rows():
+    """real_time: no resampling (data_processing.py:54-62, 73-82); the reference's own irregular example inputs/test_lmd.csv
+    against the `db` columns stored in the real_time trace made from it (window starting at row 0)."""
+    from golden_util import load_rt_trace
+
+    g = load_rt_trace("lmd1_both_irregular")
+    cfg = dict(g.cfg)
+    cfg["data_path"] = INPUTS
+    tb = build_tables_from_config(cfg)
+    n = g.tables.T
+    assert tb.T == 35041  # one row more than a year of quarter hours: 00:07
+    assert np.array_equal(tb.dates[:n], g.tables.dates)
+    assert (np.diff(tb.dates[:4]).astype(np.int64) == np.array([420, 480, 900])).all()
+    for k in ("there", "time_left", "soc_on_return"):
+        assert np.array_equal(getattr(tb, k)[:n], getattr(g.tables, k)), k
+    for k in ("delu", "tariff", "prc", "trc", "load", "pv"):
+        assert np.array_equal(getattr(tb, k)[:n], getattr(g.tables, k), equal_nan=True), k
