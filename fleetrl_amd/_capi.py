@@ -80,6 +80,7 @@ _TABLE_FIELDS = (
     # irregular time grids (real_time), all NULL / 0 otherwise
     ("dt_row", C.POINTER(C.c_double)), ("finish_row", C.POINTER(C.c_int32)), ("lookahead_row", C.POINTER(C.c_int32)),
     ("lookahead_cols", C.c_int32), ("reserved0", C.c_int32), ("second", C.POINTER(C.c_uint8)),
+    ("pick_rows", C.POINTER(C.c_int32)), ("n_pick_rows", C.c_int32), ("reserved1", C.c_int32),
 )
 
 
@@ -115,6 +116,8 @@ def pack_tables(tables, time_feat: np.ndarray | None):
         t.lookahead_row = ptr(irr["lookahead_row"], np.int32, C.c_int32)
         t.lookahead_cols = int(irr["lookahead_row"].shape[1])
         t.second = ptr(irr["second"], np.uint8, C.c_uint8)
+        t.pick_rows = ptr(irr["pick_rows"], np.int32, C.c_int32)
+        t.n_pick_rows = int(irr["pick_rows"].size)
     return t, keep
 
 

@@ -111,7 +111,12 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (t->lookahead_row && (t->lookahead_cols < p->price_lookahead || t->lookahead_cols < p->bl_pv_lookahead))
     return "lookahead_cols smaller than a look-ahead";
   if (p->real_time && p->log_data) return "log_data is not available with real_time (only the last skipped row would be logged)";
-  if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > p->table_rows - 1) return "start range outside the table";
+  if (t->pick_rows && t->n_pick_rows < 1) return "empty pick_rows";
+  if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > (t->pick_rows ? t->n_pick_rows : p->table_rows) - 1)
+    return "start range outside the table";
+  if (t->pick_rows)
+    for (int i = 0; i < t->n_pick_rows; ++i)
+      if (t->pick_rows[i] < 0 || t->pick_rows[i] > p->table_rows - 1) return "pick_rows entry outside the table";
   if (!t->there || !t->time_left || !t->soc_on_return || !t->delu || !t->tariff || !t->prc || !t->trc || !t->load ||
       !t->pv || !t->hour || !t->minute || !t->month || !t->weekday)
     return "a required table pointer is null";
@@ -332,6 +337,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     cd.step_s = (int)std::llround(p->dt * 3600.0);
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
+  if (t->pick_rows)
+    if ((rc = dev_upload(b, &cd.pick_rows, t->pick_rows, (size_t)t->n_pick_rows))) return rc;
   if (t->finish_row) {  // irregular time grid (real_time): episode-end row by date (the per-row step length is in PhysRow)
     if ((rc = dev_upload(b, &d.tab_finish, t->finish_row, (size_t)T))) return rc;
     HIP_TRY(b, hipStreamSynchronize(b->stream));

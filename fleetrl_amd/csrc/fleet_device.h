@@ -138,6 +138,7 @@ struct FleetCold {
   int sched_n;
   int normalize;
   const int32_t* sched;  // [sched_n, E]
+  const int32_t* pick_rows;  // candidate start rows of the pickers (start_lo / start_hi index into it), or nullptr
   // FLEET_ACT_POLICY_NIGHT (benchmarking/night_charging.py:50-98)
   const uint16_t* tab_hm;  // [T] hour << 8 | minute of the table row
   int32_t* night_start;    // [E] row at which the env's charging window opened, FLEET_NIGHT_IDLE when closed

@@ -118,10 +118,13 @@ __device__ __forceinline__ uint32_t philox_start(unsigned long long seed, uint32
 
 __device__ __forceinline__ int choose_start(const FleetCold* cd, int E, int e, int episode) {
   if (cd->sched_n > 0) return cd->sched[(size_t)(episode % cd->sched_n) * E + e];
-  if (cd->picker_mode == FLEET_PICK_STATIC) return cd->start_lo;
-  const uint32_t range = (uint32_t)(cd->start_hi - cd->start_lo + 1);
-  const uint32_t x = philox_start(cd->seed, (uint32_t)(cd->env_id_offset + e), (uint32_t)episode);
-  return cd->start_lo + (int)__umulhi(x, range);
+  int k = cd->start_lo;
+  if (cd->picker_mode != FLEET_PICK_STATIC) {
+    const uint32_t range = (uint32_t)(cd->start_hi - cd->start_lo + 1);
+    const uint32_t x = philox_start(cd->seed, (uint32_t)(cd->env_id_offset + e), (uint32_t)episode);
+    k += (int)__umulhi(x, range);
+  }
+  return cd->pick_rows ? cd->pick_rows[k] : k;  // candidate list of the pickers' date_range on an irregular grid
 }
 
 // ScoreConfig.soc_violation_penalty (score_config.py:26-30)

@@ -87,7 +87,10 @@ def irregular_grid_tables(tables: FleetTables, rc: ResolvedConfig) -> dict:
         r = np.searchsorted(d, hour0 + j * 3600)  # first row at or after the top of that hour ...
         ok = (r < T) & (d[np.clip(r, 0, T - 1)] < hour0 + (j + 1) * 3600)  # ... that still lies inside it
         look[:, j - 1] = np.where(ok, r, -1)
-    return dict(dt_row=dt, finish_row=finish, lookahead_row=look, second=(d % 60).astype(np.uint8))
+    # rows the reference's pickers can draw: pd.date_range(min_date, ..., freq) -- the model-frequency grid anchored at the
+    # first date (random_time_picker.py:25-28, eval_time_picker.py:33-36); off-grid rows are never start rows
+    on_grid = np.nonzero((d - d[0]) % (rc.minutes * 60) == 0)[0].astype(np.int32)
+    return dict(dt_row=dt, finish_row=finish, lookahead_row=look, second=(d % 60).astype(np.uint8), pick_rows=on_grid)
 
 
 def time_features(tables: FleetTables) -> np.ndarray:
@@ -130,6 +133,23 @@ def picker_range(rc: ResolvedConfig, tables: FleetTables) -> tuple[int, int]:
     random: `pd.date_range(min, max - end_cutoff days, freq)`  (random_time_picker.py:25-28)
     eval  : `pd.date_range(max - end_cutoff days, max - 2*episode_length hours, freq)` (eval_time_picker.py:33-36)
     static: the single row of `StaticTimePicker`."""
+    irr = tables.meta.get("irregular")
+    if irr is not None:
+        # irregular grid: the same date arithmetic, as INDICES into the candidate list `pick_rows` (on-grid rows)
+        d = tables.dates.astype("datetime64[s]").astype(np.int64)
+        cand = d[irr["pick_rows"]]
+
+        def last_at_or_before(ts):
+            return int(np.searchsorted(cand, ts, side="right") - 1)
+
+        if rc.time_picker == "static":
+            k = int(np.searchsorted(irr["pick_rows"], static_start_row(tables)))
+            return k, k
+        cut = last_at_or_before(d[-1] - rc.end_cutoff * 86400)
+        if rc.time_picker == "random":
+            return 0, cut
+        first_eval = int(np.searchsorted(cand, d[-1] - rc.end_cutoff * 86400, side="left"))
+        return first_eval, last_at_or_before(d[-1] - 2 * rc.episode_length * 3600)
     T = tables.T
     sph = 60 // rc.minutes
     if rc.time_picker == "static":
@@ -160,6 +180,17 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     validate_supported(rc)
     n = tables.N
     sph = 60 // rc.minutes
+    step = np.diff(tables.dates.astype("datetime64[s]").astype(np.int64))
+    if step.size and not np.all(step == rc.minutes * 60):
+        if not rc.real_time:
+            raise ValueError(f"table rows must be {rc.minutes} min apart unless real_time=True (the reference resamples "
+                             "the schedule to the model frequency otherwise, data_processing.py:54-62)")
+        if not (rc.include_building and rc.include_pv):
+            raise ValueError("an irregular time grid only runs with include_building and include_pv in the reference (the "
+                             "other observers look the window end up by exact date, observer_price_only.py:51); unsupported")
+        tables.meta["irregular"] = irregular_grid_tables(tables, rc)  # travels to the library through _capi.pack_tables
+    else:
+        tables.meta.pop("irregular", None)
     ext = table_extrema(tables) if extrema is None else extrema
     max_load = ext["max_load"] if rc.include_building else 0  # fleet_environment.py:265-268
     grid, evse, batt = rc.company(n, max_load)
@@ -186,17 +217,6 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     p.auto_reset = int(auto_reset)
     p.env_id_offset = int(env_id_offset)
     p.log_data = int(bool(rc.raw.get("log_data", False)))
-    step = np.diff(tables.dates.astype("datetime64[s]").astype(np.int64))
-    if step.size and not np.all(step == rc.minutes * 60):
-        if not rc.real_time:
-            raise ValueError(f"table rows must be {rc.minutes} min apart unless real_time=True (the reference resamples "
-                             "the schedule to the model frequency otherwise, data_processing.py:54-62)")
-        if not (rc.include_building and rc.include_pv):
-            raise ValueError("an irregular time grid only runs with include_building and include_pv in the reference (the "
-                             "other observers look the window end up by exact date, observer_price_only.py:51); unsupported")
-        tables.meta["irregular"] = irregular_grid_tables(tables, rc)
-    else:
-        tables.meta.pop("irregular", None)
     p.real_time = int(rc.real_time)
     s = rc.seed if seed is None else seed
     p.seed = int(s) if s is not None else 0

@@ -165,6 +165,12 @@ typedef struct FleetTables {
   int32_t lookahead_cols;       /* >= max(price_lookahead, bl_pv_lookahead)                                           */
   int32_t reserved0;
   const uint8_t* second;        /* [T]  seconds of the row's clock time (the clock-minute-15 event needs second == 0) */
+  /* Candidate start rows of the random / eval time pickers, or NULL (= every row of [start_lo, start_hi]).  The
+   * reference draws from a `date_range` at the model frequency (random_time_picker.py:25-28), which on an irregular
+   * grid is a subset of the rows; with this list FleetParams.start_lo / start_hi index INTO it. */
+  const int32_t* pick_rows;     /* [n_pick_rows] ascending row numbers */
+  int32_t n_pick_rows;
+  int32_t reserved1;
 } FleetTables;
 
 typedef struct FleetEnvBatch* fleet_handle;

@@ -37,3 +37,33 @@ def test_real_time_multi_step_entries_are_refused():
     with pytest.raises(FleetHipError, match="real_time"):
         hip.rollout_policy_dev(POLICY_UNCONTROLLED, 4, obs.data_ptr(), rs.data_ptr())
     hip.close()
+
+
+def test_irregular_grid_random_picker_matches_oracle():
+    """Random picker on the irregular example: HIP and oracle draw the same on-grid start rows (candidate list) and stay in
+    lock-step through the event-skipping steps."""
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+    from test_real_time_oracle import _irregular_random_params
+
+    g, rc, p = _irregular_random_params(64)
+    cand = g.tables.meta["irregular"]["pick_rows"]
+    p.start_lo, p.start_hi = 0, int(cand.size) - 1 - 2 * 96
+    hip, cpu = FleetBatch(p, g.tables, g.time_feat), OracleBatch(p, g.tables, g.time_feat)
+    np.testing.assert_allclose(hip.reset(), cpu.reset(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))
+    assert np.isin(hip.get("start_idx"), cand).all()
+    rng = np.random.default_rng(2)
+    for s in range(60):
+        a = rng.uniform(-1, 1, size=(64, g.N)).astype(np.float32)
+        a[rng.random(a.shape) < 0.5] = 0.0
+        oh, rh, dh, _ = hip.step(a)
+        oc, rc_, dc, _ = cpu.step(a)
+        np.testing.assert_array_equal(dh, dc)
+        np.testing.assert_allclose(rh, rc_, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(hip.get("time_idx"), cpu.get("time_idx"))
+    np.testing.assert_array_equal(hip.get("start_idx"), cpu.get("start_idx"))
+    hip.check_errors()
+    hip.close()
+    cpu.close()
