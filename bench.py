@@ -249,7 +249,7 @@ def main():
                        "envs_per_gpu": E, "evs_per_env": N, "obs_dim": batch.obs_dim, "launch": "hipGraph" if use_graph else "eager", "prime_ms": args.prime_ms,
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_env_step": bytes_step, "bytes_per_launch": bytes_step * E,
                          "kernel_ms_event_pair_per_launch": float(np.mean(per))},
             # K steps per launch: only the last step's observation is part of the result (and written), so the
