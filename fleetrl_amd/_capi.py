@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -43,16 +43,13 @@ FIELDS = {
     "done": (17, np.uint8, False),
     "episodes": (18, np.int32, False),
     "penalty_record": (19, np.float64, False),
-    "log_overload": (20, np.float64, False),
-    "log_soc_missing": (21, np.float64, False),
-    "log_energy": (22, np.float64, True),
 }
 
 _I32_FIELDS = (
     "abi_version", "struct_bytes", "num_envs", "num_cars", "table_rows", "episode_steps", "price_lookahead",
     "bl_pv_lookahead", "steps_per_hour", "hour_phase", "include_building", "include_pv", "aux", "normalize",
     "is_caretaker", "deg_mode", "picker_mode", "start_lo", "start_hi", "auto_reset", "env_id_offset", "log_data",
-    "real_time", "reserved0",
+    "real_time", "log_capacity",
 )
 _F64_FIELDS = (
     "dt", "evse_power", "obc_max_power", "batt_cap_nominal", "init_battery_cap", "grid_connection",
@@ -169,6 +166,10 @@ def load_library():
     lib.fleet_last_error.argtypes = [vp]
     lib.fleet_last_error.restype = C.c_char_p
     lib.fleet_set_stream.argtypes = [vp, vp]
+    lib.fleet_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.fleet_log_capacity.argtypes = [vp]
+    lib.fleet_log_read.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.fleet_log_clear.argtypes = [vp]
     lib.fleet_synchronize.argtypes = [vp]
     lib.fleet_set_start_schedule.argtypes = [vp, vp, C.c_int]
     lib.fleet_reset_dev.argtypes = [vp, u8p, f32p]
@@ -186,7 +187,8 @@ def load_library():
     lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
-    for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_synchronize", "fleet_set_start_schedule",
+    for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_log_capacity", "fleet_log_read",
+                 "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
                  "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev"):
@@ -196,7 +198,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = (
-    "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_synchronize",
+    "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_get_stream", "fleet_synchronize",
+    "fleet_log_capacity", "fleet_log_read", "fleet_log_clear",
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev",
     "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",

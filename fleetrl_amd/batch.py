@@ -56,6 +56,43 @@ class FleetBatch:
     def set_stream(self, hip_stream: int):
         self._check(self.lib.fleet_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def stream_ptr(self) -> int:
+        """The hipStream_t the handle launches on (an integer address)."""
+        out = C.c_void_p()
+        self._check(self.lib.fleet_get_stream(self.h, C.byref(out)))
+        return int(out.value or 0)
+
+    def use_torch_stream(self, device=None):
+        """Launch on torch's current stream of the handle's device from now on: launches are then ordered with the torch ops
+        that produce their inputs and consume their outputs (the handle's own stream is non-blocking, i.e. NOT ordered with
+        torch's).  Call again after switching torch streams."""
+        import torch
+
+        dev = torch.device("cuda", self.device) if device is None else device
+        self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    # ---- device-side data log (FleetParams.log_data) -----------------------------------------------------------
+    def log_capacity(self) -> int:
+        return int(self.lib.fleet_log_capacity(self.h))
+
+    def log_read(self, with_obs: bool = True):
+        """-> dict(pos i32[E], row i32[cap,E], env f64[cap,E,4], ev f64[cap,E,4,N], obs f32[cap,E,obs_dim] | None): the whole
+        ring in one transfer per array (layout: include/fleet_hip.h, fleet_log_read)."""
+        cap = self.log_capacity()
+        if cap <= 0:
+            raise FleetHipError(_capi.ERR_INVALID, "the data log is off (log_data = 0)")
+        pos = np.zeros(self.E, dtype=np.int32)
+        row = np.zeros((cap, self.E), dtype=np.int32)
+        env = np.zeros((cap, self.E, 4))
+        ev = np.zeros((cap, self.E, 4, self.N))
+        obs = np.zeros((cap, self.E, self.obs_dim), dtype=np.float32) if with_obs else None
+        self._check(self.lib.fleet_log_read(self.h, pos.ctypes.data, row.ctypes.data, env.ctypes.data, ev.ctypes.data,
+                                             None if obs is None else obs.ctypes.data))
+        return {"pos": pos, "row": row, "env": env, "ev": ev, "obs": obs, "capacity": cap}
+
+    def log_clear(self):
+        self._check(self.lib.fleet_log_clear(self.h))
+
     def set_start_schedule(self, starts):
         if starts is None:
             self._check(self.lib.fleet_set_start_schedule(self.h, None, 0))

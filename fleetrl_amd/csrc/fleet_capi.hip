@@ -103,6 +103,18 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
+  // the rainflow stack indices travel in 13-bit fields of the hot record (fleet_device.h HOT_PACK)
+  if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps + 3 > FLEET_MAX_STACK_ROWS)
+    return "rainflow/SEI degradation: episode_steps + 3 exceeds 8191 (the packed rainflow stack indices are 13 bits wide)";
+  if (t->finish_row)
+    for (int r = 0; r < p->table_rows; ++r) {
+      if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
+      if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r + 3 > FLEET_MAX_STACK_ROWS)
+        return "rainflow/SEI degradation: an episode spans more than 8188 rows (the packed rainflow stack indices are 13 bits wide)";
+    }
+  if (t->lookahead_row)
+    for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
+      if (t->lookahead_row[k] >= p->table_rows) return "lookahead_row entry outside the table";
   if (p->normalize && p->include_pv && !p->include_building)
     return "normalize with pv but without building load crashes in the reference (quirk Q4); unsupported";
   if ((t->dt_row != nullptr) != (t->finish_row != nullptr) || (t->dt_row && (!t->lookahead_row || t->lookahead_cols < 1)))
@@ -110,7 +122,8 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (t->dt_row && !p->real_time) return "an irregular time grid needs real_time = 1";
   if (t->lookahead_row && (t->lookahead_cols < p->price_lookahead || t->lookahead_cols < p->bl_pv_lookahead))
     return "lookahead_cols smaller than a look-ahead";
-  if (p->real_time && p->log_data) return "log_data is not available with real_time (only the last skipped row would be logged)";
+  if (p->real_time && p->log_data) return "log_data is not available with real_time";
+  if (p->log_capacity < 0) return "negative log_capacity";
   if (t->pick_rows && t->n_pick_rows < 1) return "empty pick_rows";
   if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > (t->pick_rows ? t->n_pick_rows : p->table_rows) - 1)
     return "start range outside the table";
@@ -283,7 +296,13 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.E = E; d.N = N; d.T = T;
   d.obs_dim = obs_dim_of(p);
   d.episode_steps = p->episode_steps;
-  d.stack_cap = p->episode_steps + 3;
+  // rows of the rainflow stack workspace: pushes <= logged samples; on an irregular grid an episode spans as many rows as its
+  // finish row says, not episode_steps
+  int max_rows = p->episode_steps;
+  if (t->finish_row)
+    for (int r = 0; r < T; ++r)
+      if (t->finish_row[r] - r > max_rows) max_rows = t->finish_row[r] - r;
+  d.stack_cap = max_rows + 3;
   d.tail_a_len = 2 * (L + 1) + (p->include_building ? B + 1 : 0) + (p->include_pv ? B + 1 : 0);
   d.tail_b_len = p->aux ? (1 + (p->include_building ? 3 : 0) + 6) : 0;
   d.tail_stride = ((d.tail_a_len + d.tail_b_len + 3) / 4) * 4;
@@ -353,9 +372,14 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &d.soh, EN))) return rc;
   if ((rc = dev_alloc(b, &d.soc_deg, EN))) return rc;
   if ((rc = dev_alloc(b, &d.sei, EN))) return rc;
-  if (p->log_data) {
-    if ((rc = dev_alloc(b, &d.log_env, (size_t)E * 2))) return rc;
-    if ((rc = dev_alloc(b, &d.log_energy, EN))) return rc;
+  if (p->log_data) {  // device-side data log: ring of log_capacity rows per env (default: two episodes incl. their reset rows)
+    d.log_cap = p->log_capacity > 0 ? p->log_capacity : 2 * (p->episode_steps + 1);
+    const size_t rows = (size_t)d.log_cap * E;
+    if ((rc = dev_alloc(b, &d.log_pos, (size_t)E))) return rc;
+    if ((rc = dev_alloc(b, &d.log_row, rows))) return rc;
+    if ((rc = dev_alloc(b, &d.log_env, rows * 4))) return rc;
+    if ((rc = dev_alloc(b, &d.log_ev, rows * 4 * N))) return rc;
+    if ((rc = dev_alloc(b, &d.log_obs, rows * (size_t)d.obs_dim))) return rc;
   }
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
@@ -529,15 +553,8 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
     return FLEET_ERR_INVALID;
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  if (K == 1) {
-    // K == 1 writes per-step reward/done; keep the many-step contract (sum / count) by using the staging done buffer
-    HIP_TRY(h, fleet_launch_step(h->d, actions, act_dtype, 1, obs, reward_sum, h->st_done, nullptr, nullptr, h->stream));
-    if (done_count) {
-      h->error = "fleet_step_many_dev: done_count needs K >= 2";
-      return FLEET_ERR_INVALID;
-    }
-    return FLEET_OK;
-  }
+  // K == 1 without done_count is the single-step kernel (it writes the per-step reward = the sum of one, and the done flag
+  // to the staging buffer); with done_count the launcher takes the multi-step kernel, which counts episode ends
   HIP_TRY(h, fleet_launch_step(h->d, actions, act_dtype, K, obs, reward_sum, h->st_done, nullptr, done_count, h->stream));
   return FLEET_OK;
 }
@@ -633,10 +650,10 @@ static size_t field_bytes(const FleetDev& d, int field) {
   size_t bytes = 0;
   switch (field) {
     case FLEET_F_SOC: case FLEET_F_SOH: case FLEET_F_SOC_DEG: case FLEET_F_TARGET_SOC: case FLEET_F_FD_CYC:
-    case FLEET_F_FD_CAL: case FLEET_F_SEI_L: case FLEET_F_LOG_ENERGY: bytes = EN * 8; break;
+    case FLEET_F_FD_CAL: case FLEET_F_SEI_L: bytes = EN * 8; break;
     case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: bytes = EN * 4; break;
     case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD:
-    case FLEET_F_LOG_OVERLOAD: case FLEET_F_LOG_SOC_MISSING: bytes = E * 8; break;
+    bytes = E * 8; break;
     case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
     case FLEET_F_EPISODES: bytes = E * 4; break;
     case FLEET_F_DONE: bytes = E; break;
@@ -676,6 +693,38 @@ int fleet_get_dist_factor(fleet_handle h, double* out) {
   HIP_TRY(h, fleet_launch_dist_factor(h->d, h->st_dist, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out, h->st_dist, (size_t)h->d.E * h->d.N * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FLEET_OK;
+}
+
+int fleet_log_capacity(fleet_handle h) { return (h && h->d.log_pos) ? h->d.log_cap : 0; }
+
+int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs) {
+  if (!h || !h->d.log_pos) {
+    if (h) h->error = "fleet_log_read: the data log is off (FleetParams.log_data = 0)";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const FleetDev& d = h->d;
+  const size_t rows = (size_t)d.log_cap * d.E;
+  if (pos) HIP_TRY(h, hipMemcpyAsync(pos, d.log_pos, (size_t)d.E * 4, hipMemcpyDeviceToHost, h->stream));
+  if (row) HIP_TRY(h, hipMemcpyAsync(row, d.log_row, rows * 4, hipMemcpyDeviceToHost, h->stream));
+  if (env) HIP_TRY(h, hipMemcpyAsync(env, d.log_env, rows * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+  if (ev) HIP_TRY(h, hipMemcpyAsync(ev, d.log_ev, rows * 4 * d.N * 8, hipMemcpyDeviceToHost, h->stream));
+  if (obs) HIP_TRY(h, hipMemcpyAsync(obs, d.log_obs, rows * (size_t)d.obs_dim * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FLEET_OK;
+}
+
+int fleet_log_clear(fleet_handle h) {
+  if (!h || !h->d.log_pos) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemsetAsync(h->d.log_pos, 0, (size_t)h->d.E * 4, h->stream));
+  return FLEET_OK;
+}
+
+int fleet_get_stream(fleet_handle h, void** hip_stream) {
+  if (!h || !hip_stream) return FLEET_ERR_INVALID;
+  *hip_stream = static_cast<void*>(h->stream);
   return FLEET_OK;
 }
 

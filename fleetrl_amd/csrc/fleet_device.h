@@ -80,16 +80,17 @@ struct Hot {
 #define HOT_FROZEN(b) ((((b) >> 28) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define HOT_PACK(tail, head, sgn, frozen, there, t090)                                                       \
-  ((uint32_t)(tail) | ((uint32_t)(head) << 13) | ((uint32_t)(sgn) << 26) | ((frozen) ? 0x10000000u : 0u) | \
-   ((uint32_t)(there) << 30) | ((t090) ? 0x80000000u : 0u))
+#define FLEET_MAX_STACK_ROWS 8191  // 13-bit tail / head: fleet_create rejects longer episodes in rainflow mode
+#define HOT_PACK(tail, head, sgn, frozen, there, t090)                                                                     \
+  (((uint32_t)(tail) & 0x1FFFu) | (((uint32_t)(head) & 0x1FFFu) << 13) | (((uint32_t)(sgn) & 3u) << 26) |                \
+   ((frozen) ? 0x10000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
 
 // Env record, 64 B = one cache line: the 16-byte head every lane of the group needs (wave-uniform for G == 64),
 // followed by the episode statistics only the group's leader lane touches.  One pointer, one line per env and step
 // (separate planes cost a pointer pair and a cache line each).
 struct EnvHead {
   int32_t t;         // current table row (episode.time)
-  int32_t t_end;     // finish row (episode.finish_time); the start row is t_end - episode_steps
+  int32_t t_end;     // finish row (episode.finish_time)
   int32_t nsamp;     // len(LogDataDeg.soc_log)
   int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
 };
@@ -98,7 +99,7 @@ struct EnvRec {
   int32_t ep_len;          // steps taken in the running episode
   int32_t last_ep_len;     // length of the last finished episode
   uint32_t err;            // FLEET_DEVERR_* bits
-  int32_t done;            // episode.done
+  int32_t start_done;      // [30:0] row the running episode started on (episode.start_time), [31] episode.done
   double ep_return;        // episode.cumulative_reward
   double last_ep_return;   // return of the last finished episode
   double cashflow;         // episode.current_charging_expense (last step)
@@ -177,8 +178,15 @@ struct FleetDev {
   RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
-  double* log_env;    // [E][2] {overload_amount, cum_soc_missing} of the last step, or nullptr (log_data off)
-  double* log_energy; // [E,N] (dis)charging energy of the last step, or nullptr
+  // device-side data log (FleetParams.log_data; utils/data_logger/data_logger.py:21-68): a ring of `log_cap` rows per env,
+  // written by the kernels in every mode (single step, K-step, policy rollout, reset); env e's next row goes to slot
+  // log_pos[e] % log_cap.  All nullptr / 0 when log_data is off.
+  int log_cap;
+  int32_t* log_pos;   // [E] rows written so far
+  int32_t* log_row;   // [log_cap][E] table row of episode.time; bit 31: the row reset() writes (fleet_environment.py:420-432)
+  double* log_env;    // [log_cap][E][4] reward, cashflow, overload_amount, cum_soc_missing (:659-661)
+  double* log_ev;     // [log_cap][E][4][N] action, (dis)charging energy (ev_charger.py:114,174), degradation, soh
+  float* log_obs;     // [log_cap][E][obs_dim] the (normalised) observation of the row
   double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfAcc (4 doubles) followed by the reversal stack, EV-major
                       // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators + the
                       // stack entries around the top) instead of one line per field / stack level

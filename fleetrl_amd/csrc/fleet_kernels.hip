@@ -29,7 +29,7 @@
 #include "fleet_device.h"
 
 #ifdef FLEET_STAMPS
-// Diagnostic build only (tools/stamps.py): s_memtime stamps of wave 0 of every workgroup at fixed points of the step,
+// Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave (the first 4096) at fixed points of the step,
 // written to a buffer nothing else reads.  Never compiled into the product library.
 __device__ unsigned long long fleet_stamp_buf[4096 * 16];
 #define FLEET_STAMP(k)                                                                                   \
@@ -38,7 +38,8 @@ __device__ unsigned long long fleet_stamp_buf[4096 * 16];
     unsigned long long _t;                                                                               \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                           \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) fleet_stamp_buf[blockIdx.x * 16 + (k)] = _t;             \
+    const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
+    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 16 + (k)] = _t;                       \
   } while (0)
 extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet_stamp_buf), sizeof(fleet_stamp_buf));
@@ -250,9 +251,11 @@ __device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restr
 // ---------------------------------------------------------------------------------------------------------
 // battery degradation
 // ---------------------------------------------------------------------------------------------------------
-// exp(z) for |z| <= 0.55 by its Taylor polynomial (degree 14: truncation < 2e-15 relative).  Used where the
-// argument range is known a priori, instead of the general (and far longer) library exp.
+// exp(z) by its Taylor polynomial of degree 14: truncation < 2e-15 relative for |z| <= 0.55 (a mean SOC in [0, 1]) and
+// < 8e-13 for |z| <= 1; beyond that -- a mean SOC far outside [0, 1], which the reference does not clip (quirk Q9) and a
+// schedule whose trips use more than a battery charge can produce -- the library exp takes over.
 __device__ __forceinline__ double exp_small(double z) {
+  if (fabs(z) > 1.0) return exp(z);
   double r = 1.0 / 87178291200.0;  // 1/14!
   r = fma(r, z, 1.0 / 6227020800.0);
   r = fma(r, z, 1.0 / 479001600.0);
@@ -458,8 +461,9 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // ---------------------------------------------------------------------------------------------------------
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
+// `lp`: the env's data-log cursor (rows written so far; only used when the log is on), advanced by the row reset() writes.
 template <int G>
-__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row) {
+__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
   const int N = d.N;
   const size_t EN = (size_t)d.E * N;
   const FleetCold* cd = d.cold;
@@ -467,6 +471,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   r.t = start;
   r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
   r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
+  // data log: the row reset() writes -- time, observation and SoH, zeros for everything else (:420-432)
+  const size_t lrow = d.log_pos ? (size_t)(lp % d.log_cap) * d.E + e : 0;
+  float* const log_obs_row = d.log_pos ? d.log_obs + lrow * d.obs_dim : nullptr;
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
     const TabX tx = d.tab[ti];
@@ -504,15 +511,32 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       row[4] = soc_deg;
     }
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
+    if (d.log_pos) {
+      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb, ar);
+      double* lev = d.log_ev + lrow * 4 * N + c;
+      lev[0] = 0.0;
+      lev[N] = 0.0;
+      lev[2 * N] = 0.0;
+      lev[3 * N] = soh;
+    }
   }
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
+  if (d.log_pos) {
+    write_obs_tail<G>(d, log_obs_row, start, g);
+    if (leader) {
+      d.log_row[lrow] = (int32_t)((uint32_t)start | 0x80000000u);
+      double* le = d.log_env + lrow * 4;
+      le[0] = le[1] = le[2] = le[3] = 0.0;
+    }
+    lp += 1;
+  }
   if (leader) {
     EnvRec* er = d.env + e;
     er->h = r;
     er->ep_return = 0.0;
     er->ep_len = 0;
     er->penalty_record = 0.0;
-    er->done = 0;
+    er->start_done = start;  // bit 31 (episode.done) cleared
     if (r.t_end > d.T - 1) atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
   }
 }
@@ -525,8 +549,10 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   if (mask && !mask[e]) return;
   EnvHead r = d.env[e].h;
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
-  if (d.env[e].ep_len > 0 && !d.env[e].done) r.episodes += 1;
-  reset_env<G>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr);
+  if (d.env[e].ep_len > 0 && d.env[e].start_done >= 0) r.episodes += 1;
+  int lp = d.log_pos ? d.log_pos[e] : 0;
+  reset_env<G>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
+  if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -614,6 +640,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     if (G == 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
   }
 
+  // data log cursor of the env (rows written so far), carried in a register over the launch's steps
+  int lp = d.log_pos ? d.log_pos[e] : 0;
+  if (G == 64) lp = __builtin_amdgcn_readfirstlane(lp);
+
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
   const bool rt = MULTI && (d.real_time != 0);
@@ -652,7 +682,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
 #endif
 
-    const float tail_first = write_step_obs ? tail_load<G>(d, t1, g) : 0.0f;  // consumed after the lane loop
+    // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
+    // buffer, so K-step launches log every step although they only return the last observation
+    const bool logs = d.log_pos && env_ok && !is_done;
+    const size_t lrow = logs ? (size_t)(lp % d.log_cap) * d.E + e : 0;
+    float* const log_obs_row = logs ? d.log_obs + lrow * d.obs_dim : nullptr;
+
+    const float tail_first = (write_step_obs || logs) ? tail_load<G>(d, t1, g) : 0.0f;  // consumed after the lane loop
 
     // Multi-step launches: an opaque per-iteration zero keeps the compiler from hoisting every lane address of the step
     // body out of the K loop (60 extra live vector registers = half the resident wavefronts); recomputing them each
@@ -760,7 +796,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
       rew += pos ? ph.k_charge * grid_e : ph.k_discharge * en;   // :154-156 / :204-206
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
-      if (d.log_energy && env_ok) d.log_energy[i] = en;  // DataLogger "Charging energy" input (log_data only)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
       const float ntl = tb1.tl;
@@ -790,6 +825,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
 #ifndef FLEET_ABL_NO_OBS
       if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
+      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1, ar);
 #endif
 
       FLEET_STAMP(4);
@@ -808,6 +844,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         }
       }
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
+      if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
+        double* lev = d.log_ev + lrow * 4 * N + c;
+        lev[0] = a;
+        lev[N] = en;
+        lev[2 * N] = soh0 - soh;
+        lev[3 * N] = soh;
+      }
 
       FLEET_STAMP(5);
       if (env_ok) {
@@ -828,6 +871,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     }
 #ifndef FLEET_ABL_NO_OBS
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
+    if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
 #endif
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
@@ -839,7 +883,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     asum = group_sum_to_last<G>(asum);
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
 #endif
-    if (d.log_env) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
+    if (d.log_pos) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
       penalty_record += penrec;
@@ -852,9 +896,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         penalty_record += pen;
         if (MULTI) ev_lane = true;  // :499
       }
-      if (d.log_env && env_ok) {
-        d.log_env[2 * (size_t)e] = over;          // grid = abs(overload_amount) (:660)
-        d.log_env[2 * (size_t)e + 1] = miss_sum;  // soc_v = abs(cum_soc_missing) (:661)
+      if (logs) {
+        d.log_row[lrow] = t1;  // episode.time
+        double* le = d.log_env + lrow * 4;
+        le[0] = rew;
+        le[1] = cash;
+        le[2] = over;      // grid = abs(overload_amount) (:660)
+        le[3] = miss_sum;  // soc_v = abs(cum_soc_missing) (:661)
       }
       ep_return += rew;  // :637
       ep_len += 1;
@@ -883,10 +931,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         const Hot hb = d.hot[i];
         const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
         const RfTop top = d.rf_top[i];
-        d.soh[i] = d.soh[i] - sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
+        const double deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
+        const double soh_new = d.soh[i] - deg;
+        d.soh[i] = soh_new;
+        if (logs) {
+          double* lev = d.log_ev + lrow * 4 * N + c;
+          lev[2 * N] = deg;
+          lev[3 * N] = soh_new;
+        }
         if (!WIDE) break;
       }
     }
+    if (logs) lp += 1;
 #ifdef FLEET_ABL_NO_RARE
     if (false) {
 #else
@@ -897,12 +953,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         EnvRec* er = d.env + e;
         er->last_ep_return = ep_return;
         er->last_ep_len = ep_len;
-        er->done = 1;
+        er->start_done |= (int32_t)0x80000000u;  // episode.done
       }
       r.episodes += 1;
       if (resets) {
         if (env_ok) {
-          reset_env<G>(*d.self, e, g, leader, r, obs_row);
+          reset_env<G>(*d.self, e, g, leader, r, obs_row, lp);
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;
@@ -929,6 +985,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     er->ep_return = ep_return;
     er->ep_len = ep_len;
     er->penalty_record = penalty_record;
+    if (d.log_pos) d.log_pos[e] = lp;
     if (MULTI) {
       reward[e] = rt ? last_rew : reward_sum;
       if (rt && done) done[e] = last_done ? 1 : 0;
@@ -959,7 +1016,7 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
   const size_t E = d.E, EN = (size_t)d.E * d.N;
   const bool per_car = field == FLEET_F_SOC || field == FLEET_F_HOURS_LEFT || field == FLEET_F_SOH || field == FLEET_F_SOC_DEG ||
                        field == FLEET_F_TARGET_SOC || field == FLEET_F_RF_LEN || field == FLEET_F_FD_CYC ||
-                       field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L || field == FLEET_F_LOG_ENERGY;
+                       field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
     case FLEET_F_SOC: ((double*)out)[i] = d.hot[i].soc; break;
@@ -974,19 +1031,16 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_FD_CAL: ((double*)out)[i] = d.sei[i].fd_cal; break;
     case FLEET_F_SEI_L: ((double*)out)[i] = d.sei[i].sei_l; break;
     case FLEET_F_TIME_IDX: ((int32_t*)out)[i] = d.env[i].h.t; break;
-    case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env[i].h.t_end - d.episode_steps; break;
+    case FLEET_F_START_IDX: ((int32_t*)out)[i] = d.env[i].start_done & 0x7FFFFFFF; break;
     case FLEET_F_CASHFLOW: ((double*)out)[i] = d.env[i].cashflow; break;
     case FLEET_F_EP_RETURN: ((double*)out)[i] = d.env[i].ep_return; break;
     case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env[i].ep_len; break;
     case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env[i].last_ep_return; break;
     case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env[i].last_ep_len; break;
     case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = d.env[i].err; break;
-    case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)d.env[i].done; break;
+    case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)(d.env[i].start_done < 0); break;
     case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].h.episodes; break;
     case FLEET_F_PENALTY_RECORD: ((double*)out)[i] = d.env[i].penalty_record; break;
-    case FLEET_F_LOG_OVERLOAD: ((double*)out)[i] = d.log_env ? d.log_env[2 * i] : 0.0; break;
-    case FLEET_F_LOG_SOC_MISSING: ((double*)out)[i] = d.log_env ? d.log_env[2 * i + 1] : 0.0; break;
-    case FLEET_F_LOG_ENERGY: ((double*)out)[i] = d.log_energy ? d.log_energy[i] : 0.0; break;
     default: break;
   }
 }

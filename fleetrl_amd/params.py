@@ -60,6 +60,9 @@ def validate_supported(rc: ResolvedConfig) -> None:
     if rc.deg_mode == DEG_RAINFLOW and rc.init_soh != 1.0:
         raise ValueError("rainflow/SEI degradation with init_soh != 1.0 is ill-defined in the reference "
                          "(rainflow_sei_degradation.py:184); unsupported")
+    if rc.deg_mode == DEG_RAINFLOW and rc.episode_length * (60 // rc.minutes if 60 % rc.minutes == 0 else 1) + 3 > 8191:
+        raise ValueError("rainflow/SEI degradation: episodes longer than 8188 steps are not supported (the streaming rainflow's "
+                         "packed stack indices are 13 bits wide; fleet_create rejects them too)")
     if 60 % rc.minutes:
         raise ValueError("minutes per step must divide 60")
 
@@ -217,6 +220,7 @@ def make_params(rc: ResolvedConfig, tables: FleetTables, num_envs: int, *, auto_
     p.auto_reset = int(auto_reset)
     p.env_id_offset = int(env_id_offset)
     p.log_data = int(bool(rc.raw.get("log_data", False)))
+    p.log_capacity = int(rc.raw.get("log_capacity", 0) or 0)  # extension key: rows per env of the device-side log ring (0 = default)
     p.real_time = int(rc.real_time)
     s = rc.seed if seed is None else seed
     p.seed = int(s) if s is not None else 0

@@ -60,57 +60,60 @@ class FleetCore:
         self._start_time_override = [None] * self.num_envs
         if start_rows is not None:
             self.batch.set_start_schedule(start_rows)
-        # DataLogger (utils/data_logger/data_logger.py): one list of row dicts per env, only when log_data is set
+        # DataLogger (utils/data_logger/data_logger.py): the rows live in a device-side ring written by the kernels
+        # (include/fleet_hip.h "device-side data log"); get_log() rebuilds the reference's DataFrame from it
         self.log_data = bool(self.rc.raw.get("log_data", False))
-        self._log_rows = [[] for _ in range(self.num_envs)]
         self._log_episode_len = self.rc.episode_length * (60 // self.rc.minutes)
 
     # -- data log (fleet_environment.py:420-432, 659-690) ---------------------------------------------------------
-    def log_reset(self, obs, mask=None):
-        """Row written by reset(): zeros for everything but time, observation and SoH (:420-432)."""
-        if not self.log_data:
-            return
-        times, soh = self.get_time(), self.batch.get("soh")
-        for i in range(self.num_envs):
-            if mask is not None and not mask[i]:
-                continue
-            self._append_log(i, times[i], obs[i], np.zeros(self.num_cars), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
-                             np.zeros(self.num_cars), soh[i])
-
-    def log_step(self, obs, actions, reward, done, soh_before):
-        """Row written by step() unless the episode just ended (:679-690).  `penalty` is the reference's
+    def get_log(self):
+        """`FleetEnv.get_log` (:741-748): the DataLogger DataFrame of every env (same columns as the reference), or None
+        when `log_data` is off.  Works after single steps, K-step launches and device-side policy rollouts alike: the rows
+        were written by the kernels; one device-to-host copy per array here.  `Penalties` is the reference's
         `reward - cashflow * price_multiplier` (quirk Q13); "Charging energy" replicates the carry-over of
-        `charging_energy + discharging_energy` across cars (quirk Q8, ev_charger.py:81-82,114,174,212)."""
+        `charging_energy + discharging_energy` across cars (quirk Q8, ev_charger.py:81-82,114,174,212); `Episode` is
+        `row_number // episode_length + 1` (data_logger.py:50).  The ring keeps the last `log_capacity` rows per env."""
         if not self.log_data:
-            return
-        b = self.batch
-        cash, over, miss, energy, soh = (b.get("cashflow"), b.get("log_overload"), b.get("log_soc_missing"),
-                                         b.get("log_energy"), b.get("soh"))
-        times, rows = self.get_time(), b.get("time_idx")
-        acts = np.asarray(actions, dtype=np.float64).reshape(self.num_envs, self.num_cars)
-        for i in range(self.num_envs):
-            if done[i]:
-                continue  # not logged; with auto-reset the env has already been reset and log_reset() adds its row
-            deg_row = self.rc.calc_deg and self.tables.hour[rows[i]] == 14 and self.tables.minute[rows[i]] == 45
-            degradation = (soh_before[i] - soh[i]) if deg_row else 0.0
-            charge_log = np.zeros(self.num_cars)
-            ce = de = 0.0
-            for c in range(self.num_cars):
-                if acts[i, c] >= 0:
-                    ce = energy[i, c]
-                else:
-                    de = energy[i, c]
-                charge_log[c] = ce + de
-            r = float(reward[i])
-            self._append_log(i, times[i], obs[i], actions[i], r, float(cash[i]), r - float(cash[i]) * self.rc.price_multiplier,
-                             abs(float(over[i])), abs(float(miss[i])), degradation, charge_log, soh[i])
+            return [None] * self.num_envs
+        import pandas as pd
 
-    def _append_log(self, i, time, obs, action, reward, cashflow, penalty, grid, soc_v, degradation, charge_log, soh):
-        rows = self._log_rows[i]
-        rows.append({"Episode": len(rows) // self._log_episode_len + 1, "Time": time, "Observation": np.array(obs, copy=True),
-                     "Action": np.array(action, copy=True), "Reward": reward, "Cashflow": cashflow, "Penalties": penalty,
-                     "Grid overloading": grid, "SOC violation": soc_v, "Degradation": degradation,
-                     "Charging energy": np.array(charge_log, copy=True), "SOH": np.array(soh, copy=True)})
+        lg = self.batch.log_read()
+        cap, pm, N = lg["capacity"], self.rc.price_multiplier, self.num_cars
+        hour, minute = self.tables.hour, self.tables.minute
+        frames = []
+        for i in range(self.num_envs):
+            pos = int(lg["pos"][i])
+            rows = []
+            for k in range(max(0, pos - cap), pos):
+                sl = k % cap
+                raw = int(lg["row"][sl, i])
+                is_reset, t = raw < 0, raw & 0x7FFFFFFF
+                rew, cash, over, miss = (float(x) for x in lg["env"][sl, i])
+                act, energy, deg, soh = lg["ev"][sl, i]
+                if is_reset:
+                    charge_log, degradation, penalty = np.zeros(N), 0.0, 0.0
+                else:
+                    charge_log = np.zeros(N)
+                    ce = de = 0.0
+                    for c in range(N):  # quirk Q8: the two energies are not cleared from car to car
+                        if act[c] >= 0:
+                            ce = energy[c]
+                        else:
+                            de = energy[c]
+                        charge_log[c] = ce + de
+                    deg_row = self.rc.calc_deg and hour[t] == 14 and minute[t] == 45
+                    degradation = deg.copy() if deg_row else 0.0
+                    penalty = rew - cash * pm
+                rows.append({"Episode": k // self._log_episode_len + 1, "Time": self._stamp(t), "Observation": lg["obs"][sl, i].copy(),
+                             "Action": act.copy(), "Reward": rew, "Cashflow": cash, "Penalties": penalty,
+                             "Grid overloading": abs(over), "SOC violation": abs(miss), "Degradation": degradation,
+                             "Charging energy": charge_log, "SOH": soh.copy()})
+            frames.append(pd.DataFrame(rows))
+        return frames
+
+    def clear_log(self):
+        if self.log_data:
+            self.batch.log_clear()
 
     # -- reference getters (fleet_environment.py:741-799), per env ----------------------------------------
     def _stamp(self, row: int):
@@ -141,15 +144,6 @@ class FleetCore:
     def get_dist_factor(self):
         return list(self.batch.dist_factor())
 
-    def get_log(self):
-        """`FleetEnv.get_log` (:741-748): the DataLogger DataFrame of every env (same columns as the reference), or None
-        when `log_data` is off."""
-        if not self.log_data:
-            return [None] * self.num_envs
-        import pandas as pd
-
-        return [pd.DataFrame(rows) for rows in self._log_rows]
-
     def clear_start_overrides(self, mask=None):
         for i in range(self.num_envs):
             if mask is None or mask[i]:
@@ -174,22 +168,15 @@ class FleetVecEnv:
 
     def reset(self):
         self.core.clear_start_overrides()
-        obs = self.core.batch.reset()
-        self.core.log_reset(obs)
-        return obs
+        return self.core.batch.reset()
 
     def step_async(self, actions):
         self._actions = actions
 
     def step_wait(self):
         acts = np.asarray(self._actions).reshape(self.num_envs, -1)
-        soh_before = self.core.batch.get("soh") if self.core.log_data else None
         obs, rew, done, term = self.core.batch.step(acts)
         dones = done.astype(bool)
-        if self.core.log_data:
-            self.core.log_step(obs, acts, rew, dones, soh_before)
-            if dones.any():
-                self.core.log_reset(obs, mask=dones)
         infos = [{} for _ in range(self.num_envs)]
         if dones.any():
             ret, ln = self.core.batch.get("last_ep_return"), self.core.batch.get("last_ep_len")
@@ -318,17 +305,13 @@ class FleetEnv:
         """:330-434 -- ignores seed/options like the reference."""
         self.core.clear_start_overrides()
         obs = self.core.batch.reset()
-        self.core.log_reset(obs)
         return obs[0], self.info
 
     def step(self, actions):
         """:436-702 -> (obs float32[obs_dim], reward float, done bool, truncated False, info {})."""
         a = np.asarray(actions)
         a = a.reshape(1, -1) if a.dtype == np.float64 else a.astype(np.float32).reshape(1, -1)
-        soh_before = self.core.batch.get("soh") if self.core.log_data else None
         obs, rew, done, _ = self.core.batch.step(a)
-        if self.core.log_data:
-            self.core.log_step(obs, a, rew, done.astype(bool), soh_before)
         return obs[0], float(rew[0]), bool(done[0]), False, self.info
 
     def close(self):

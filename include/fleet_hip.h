@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 3
+#define FLEET_ABI_VERSION 4
 
 /* status codes */
 #define FLEET_OK 0
@@ -91,13 +91,14 @@ typedef struct FleetParams {
   int32_t auto_reset;       /* 1: VecEnv semantics (done envs are reset inside the step, terminal obs reported)
                                0: gymnasium.Env semantics (obs of a done env is its terminal obs)           */
   int32_t env_id_offset;    /* global index of env 0 of this handle (multi-GPU sharding keeps RNG streams env-stable) */
-  int32_t log_data;         /* 1: keep the per-step quantities of the reference's DataLogger (utils/data_logger/data_logger.py)
-                               that are not step outputs -- grid overload, SOC missing at departure, per-EV energy -- for
-                               FLEET_F_LOG_*; 0: skip them */
+  int32_t log_data;         /* 1: device-side data log -- every row the reference's DataLogger would get
+                               (utils/data_logger/data_logger.py:21-68; call sites fleet_environment.py:420-432, 659-690) is
+                               written to a per-env ring by the kernels, in every mode (single step, K steps per launch,
+                               policy rollouts, resets); read with fleet_log_read.  0: nothing is logged */
   int32_t real_time;        /* 1: event-skipping step (fleet_environment.py:453,692-699, event_manager.py:16-31): the same
                                action is applied row after row until a relevant event (departure, arrival, penalty,
                                overload, episode end, clock minute 15); irregular time grids need FleetTables.dt_row etc. */
-  int32_t reserved0;
+  int32_t log_capacity;     /* rows per env of the data-log ring; 0 = 2 * (episode_steps + 1).  Older rows are overwritten */
   uint64_t seed;            /* Philox key for the random/eval picker */
 
   double dt;                /* hours per step (time_config.py:24) */
@@ -196,9 +197,6 @@ typedef struct FleetEnvBatch* fleet_handle;
 #define FLEET_F_DONE 17          /* u8  [E]   episode.done */
 #define FLEET_F_EPISODES 18      /* i32 [E]   finished-episode counter */
 #define FLEET_F_PENALTY_RECORD 19 /* f64 [E]  episode.penalty_record */
-#define FLEET_F_LOG_OVERLOAD 20   /* f64 [E]   last step's overload_amount [kW] (fleet_environment.py:493,660); needs log_data */
-#define FLEET_F_LOG_SOC_MISSING 21 /* f64 [E]  last step's cum_soc_missing (:544,561,579,661); needs log_data */
-#define FLEET_F_LOG_ENERGY 22     /* f64 [E,N] last step's (dis)charging energy per EV [kWh] (ev_charger.py:114,174); needs log_data */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */
@@ -206,6 +204,8 @@ int fleet_create(const FleetParams* p, const FleetTables* t, int device, fleet_h
 int fleet_destroy(fleet_handle h);
 const char* fleet_last_error(fleet_handle h);  /* h may be NULL: error of the last failed fleet_create */
 int fleet_set_stream(fleet_handle h, void* hip_stream);  /* adopt an external hipStream_t (e.g. torch's) */
+int fleet_get_stream(fleet_handle h, void** hip_stream); /* the hipStream_t the handle launches on (to order another stream
+                                                            against it with events) */
 int fleet_synchronize(fleet_handle h);
 
 /* Inject episode start rows (parity tests / `set_start_time`): `starts` is HOST [n_episodes,E]; episode k of
@@ -218,7 +218,7 @@ int fleet_reset_dev(fleet_handle h, const uint8_t* mask, float* obs);
 int fleet_step_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
                    uint8_t* done, float* terminal_obs /* [E,obs_dim] or NULL */);
 /* K consecutive steps in ONE launch for open-loop rollouts (actions known up front): actions [K,E,N];
- * obs = observation after the last step, reward_sum[E] = sum of the K rewards, done_count[E] = number of
+ * obs = observation after the last step, reward_sum[E] = sum of the K rewards, done_count[E] (or NULL) = number of
  * episode ends among them.  auto_reset must be 1. */
 int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtype, float* obs,
                         double* reward_sum, int32_t* done_count);
@@ -248,6 +248,20 @@ int fleet_get(fleet_handle h, int field, void* out_host);
 int fleet_get_dev(fleet_handle h, int field, void* out_dev);
 /* `FleetEnv.get_dist_factor` (:782-799): hours_needed / (hours_left + 0.001) from a fresh observation, f64 [E,N] */
 int fleet_get_dist_factor(fleet_handle h, double* out_host);
+/* ---- device-side data log (FleetParams.log_data = 1) ---------------------------------------------------------------
+ * What `FleetEnv.get_log()` (:741-748) returns is rebuilt from this ring: row k of env e (k counted since creation or the
+ * last fleet_log_clear; the ring holds the last `capacity` of them, row k in slot k % capacity) is
+ *   row [slot,E]      i32  table row of episode.time; bit 31 set: the row reset() writes (zeros + observation + SoH)
+ *   env [slot,E,4]    f64  reward, cashflow, overload_amount [kW], cum_soc_missing     (Penalties = reward - cashflow *
+ *                          price_multiplier and the absolute values are the caller's, :659-661)
+ *   ev  [slot,E,4,N]  f64  action, (dis)charging energy per EV [kWh] (ev_charger.py:114,174), degradation, SoH
+ *   obs [slot,E,obs_dim] f32  the observation logged with the row
+ * The step that ends an episode is not logged (:679); with auto-reset the next row is the reset row of the next episode. */
+int fleet_log_capacity(fleet_handle h);  /* rows per env; 0 when the log is off */
+/* copy the ring to HOST buffers (any of them may be NULL); pos [E] = rows written so far per env; synchronous */
+int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs);
+int fleet_log_clear(fleet_handle h);     /* forget all rows (asynchronous on the handle's stream) */
+
 /* raise FLEET_ERR_STATE if any env has device error bits set */
 int fleet_check_errors(fleet_handle h);
 

@@ -69,6 +69,30 @@ CONFIGS = {
                                        custom_ev_charger_power_in_kw=22, custom_ev_battery_size_in_kwh=40,
                                        custom_grid_connection_in_kw=120, init_battery_cap=40, obc_max_power=22,
                                        max_batt_cap_in_all_use_cases=60, log_data=True), 3, 2, 2, "full"),
+    # quirk Q7 (fleet_environment.py:263,382-392,613-618): `soh <= 0.9 -> target_soc[car] = 0.9`, sticky across resets.
+    # init_soh just above 0.9 with the linear model: cars cross on their first or second daily 14:45 call (the calendar term
+    # alone is 1.9e-7 per call), episode.soh restarts at init_soh on reset() while target_soc stays raised
+    "lmd3_price_linear_q7cross": (dict(use_case="lmd", include_building=False, include_pv=False, calculate_degradation=True,
+                                       deg_emp=True, episode_length=48, init_soh=0.9000003), 3, 2, 3, "wide"),
+    # init_soh = 0.9 exactly and no degradation: the target is raised by the very first step and the reset laxity fix-up
+    # (:382-392) of every later episode runs with 0.9; caretaker fleet, so the lunch target (:536-554) stays 0.65
+    "ct3_both_nodeg_q7sticky": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                     calculate_degradation=False, episode_length=24, init_soh=0.9), 3, 2, 3, "charge"),
+    # same with normalised observations (oracle_normalization.py:127-131 divides the raised target by the configured one)
+    "ut2_both_norm_linear_q7cross": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
+                                          normalize_in_env=True, calculate_degradation=True, deg_emp=True, episode_length=48,
+                                          init_soh=0.9000003), 2, 2, 2, "wide"),
+    # BASELINE C5 family: spot_2021 prices (year re-based by `_date_checker`, data_processing.py:419-431) and a feed-in
+    # tariff that is NOT the spot price (`load_feed_in`, :297-318; inputs/fixed_feed_in.csv)
+    "ct4_both_rainflow_spot21_feedin": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                             calculate_degradation=True, deg_emp=False, episode_length=48,
+                                             price_name="spot_2021_new.csv", tariff_name="fixed_feed_in.csv"), 4, 2, 2, "wide"),
+    "lmd3_both_linear_spot21_tariff21": (dict(use_case="lmd", building_name="load_lmd.csv", include_building=True, include_pv=True,
+                                              calculate_degradation=True, deg_emp=True, episode_length=24,
+                                              price_name="spot_2021_new.csv", tariff_name="spot_2021_new_tariff.csv"), 3, 2, 2, "wide"),
+    "ut3_both_norm_rainflow_spot21_feedin": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
+                                                  normalize_in_env=True, calculate_degradation=True, deg_emp=False, episode_length=24,
+                                                  price_name="spot_2021_new.csv", tariff_name="fixed_feed_in.csv"), 3, 2, 2, "wide"),
 }
 
 

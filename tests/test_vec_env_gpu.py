@@ -126,18 +126,23 @@ def test_data_log_matches_the_reference_logger():
     venv.reset()
     for k in range(g.total):
         venv.step(g.actions[:, k])
-    logs = venv.env_method("get_log")
+    # the reference never logs the reset that follows the last episode; our vec env has auto-reset into a third one
+    _assert_log_equals_reference(g, venv.env_method("get_log"), extra_rows=1)
+    assert (g.log_grid > 0).any() and (g.log_socv > 0).any() and (np.abs(g.log_deg) > 0).any()
+    venv.close()
+
+
+def _assert_log_equals_reference(g, logs, extra_rows):
     for e in range(g.E):
         lg = logs[e].reset_index(drop=True)
         rows = g.log_reward.shape[1]
-        # the reference never logs the reset that follows the last episode; our vec env has auto-reset into a third one
-        assert len(lg) == rows + 1
+        assert len(lg) == rows + extra_rows
         lg = lg.iloc[:rows]
         np.testing.assert_array_equal(lg["Episode"].values.astype(int), g.log_episode[e])
         np.testing.assert_array_equal(lg["Time"].values.astype("datetime64[s]").astype(np.int64), g.log_time[e])
-        np.testing.assert_allclose(lg["Reward"].values.astype(float), g.log_reward[e], rtol=1e-6, atol=1e-6)  # float32 rewards of the VecEnv
+        np.testing.assert_allclose(lg["Reward"].values.astype(float), g.log_reward[e], rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(lg["Cashflow"].values.astype(float), g.log_cashflow[e], rtol=1e-9, atol=1e-12)
-        np.testing.assert_allclose(lg["Penalties"].values.astype(float), g.log_penalty[e], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lg["Penalties"].values.astype(float), g.log_penalty[e], rtol=1e-9, atol=1e-8)
         np.testing.assert_allclose(lg["Grid overloading"].values.astype(float), g.log_grid[e], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(lg["SOC violation"].values.astype(float), g.log_socv[e], rtol=1e-9, atol=1e-12)
         for k in range(rows):
@@ -146,8 +151,83 @@ def test_data_log_matches_the_reference_logger():
             np.testing.assert_allclose(lg["SOH"].iloc[k], g.log_soh[e, k], rtol=1e-9)
             np.testing.assert_allclose(lg["Observation"].iloc[k], g.log_obs[e, k], rtol=1e-5, atol=1e-6)
             np.testing.assert_allclose(np.asarray(lg["Action"].iloc[k], dtype=np.float64), g.log_action[e, k])
-    assert (g.log_grid > 0).any() and (g.log_socv > 0).any() and (np.abs(g.log_deg) > 0).any()
+
+
+def test_data_log_is_written_by_k_step_launches_too():
+    """The reference's harnesses read the log after their policy loop (benchmarking/uncontrolled_charging.py:56,
+    night_charging.py:100).  The log is a device-side ring written by the kernels, so open-loop K-step launches
+    (`fleet_step_many_dev`) leave exactly the rows single steps would: the golden trace's actions replayed as a tape in
+    chunks of 37 steps reproduce the reference's DataLogger frame."""
+    import torch
+
+    from fleetrl_amd import FleetVecEnv
+
+    g = load_trace("custom3_both_overload_log")
+    venv = FleetVecEnv(g.cfg, g.E, tables=g.tables, start_rows=g.starts, extrema=g.extrema, start_range=(0, 0))
+    venv.reset()
+    b = venv.core.batch
+    dev = torch.device("cuda", 0)
+    tape = torch.as_tensor(np.ascontiguousarray(g.actions.transpose(1, 0, 2)), device=dev)  # [steps, E, N] float32
+    obs = torch.zeros((g.E, b.obs_dim), device=dev)
+    rsum = torch.zeros(g.E, device=dev, dtype=torch.float64)
+    dcnt = torch.zeros(g.E, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    k = 0
+    while k < g.total:
+        n = min(37, g.total - k)
+        b.step_many_dev(n, tape[k:].data_ptr(), obs.data_ptr(), rsum.data_ptr(), dcnt.data_ptr())
+        k += n
+    b.synchronize()
+    b.check_errors()
+    _assert_log_equals_reference(g, venv.env_method("get_log"), extra_rows=1)
+    # the ring keeps the newest rows: a capacity of 50 rows per env holds the tail of the same log
+    cfg = dict(g.cfg)
+    cfg["log_capacity"] = 50
+    small = FleetVecEnv(cfg, g.E, tables=g.tables, start_rows=g.starts, extrema=g.extrema, start_range=(0, 0))
+    small.reset()
+    for j in range(g.total):
+        small.step(g.actions[:, j])
+    full, tail = venv.env_method("get_log"), small.env_method("get_log")
+    for e in range(g.E):
+        assert len(tail[e]) == 50
+        ref = full[e].iloc[-50:].reset_index(drop=True)
+        for col in ("Episode", "Reward", "Cashflow", "Penalties", "Grid overloading", "SOC violation"):
+            np.testing.assert_array_equal(tail[e][col].values.astype(float), ref[col].values.astype(float), err_msg=col)
+        assert (tail[e]["Time"].values == ref["Time"].values).all()
+        for col in ("Charging energy", "SOH", "Observation", "Action"):
+            for a, r in zip(tail[e][col], ref[col]):
+                np.testing.assert_array_equal(a, r)
+    small.core.clear_log()
+    assert all(len(x) == 0 for x in small.env_method("get_log"))
     venv.close()
+    small.close()
+
+
+def test_data_log_after_a_device_side_policy_rollout():
+    """`fleet_rollout_policy_dev` (uncontrolled charging evaluated on the device, 150 steps in two launches) logs what the
+    same policy stepped from the host logs -- every column of the reference's frame, incl. the action the rule chose."""
+    from fleetrl_amd import FleetVecEnv
+    from fleetrl_amd.policies import run_policy
+
+    g = load_trace("custom3_both_overload_log")
+    kw = dict(tables=g.tables, start_rows=g.starts, extrema=g.extrema, start_range=(0, 0))
+    dev_env, host_env = FleetVecEnv(g.cfg, g.E, **kw), FleetVecEnv(g.cfg, g.E, **kw)
+    dev_env.reset()
+    host_env.reset()
+    run_policy(dev_env.core.batch, "uncontrolled", 150, chunk=96)
+    for _ in range(150):
+        host_env.step(np.ones((g.E, g.N), dtype=np.float32))
+    for a, b in zip(dev_env.env_method("get_log"), host_env.env_method("get_log")):
+        assert len(a) == len(b) > 140 and list(a.columns) == ["Episode", "Time", "Observation", "Action", "Reward", "Cashflow", "Penalties",
+                                                             "Grid overloading", "SOC violation", "Degradation", "Charging energy", "SOH"]
+        for col in ("Episode", "Reward", "Cashflow", "Penalties", "Grid overloading", "SOC violation"):
+            np.testing.assert_allclose(a[col].values.astype(float), b[col].values.astype(float), rtol=1e-12, atol=1e-12, err_msg=col)
+        assert (a["Time"].values == b["Time"].values).all()
+        for col in ("Charging energy", "SOH", "Observation", "Action", "Degradation"):
+            for x, y in zip(a[col], b[col]):
+                np.testing.assert_allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), rtol=1e-12, atol=1e-15)
+    dev_env.close()
+    host_env.close()
 
 
 def test_mixed_fleet_vec_env_equals_its_groups_stepped_separately():

@@ -34,13 +34,22 @@ lib = _capi.load_library()
 buf = np.zeros(4096 * 16, dtype=np.uint64)
 lib.fleet_debug_read_stamps.argtypes = [C.c_void_p]
 assert lib.fleet_debug_read_stamps(buf.ctypes.data) == 0
-s = buf.reshape(4096, 16)[: min(E // 4, 4096), :9].astype(np.int64)
+s = buf.reshape(4096, 16)[: min(E, 4096), :9].astype(np.int64)  # one row per wavefront (G = 64: one env each)
 names = ["entry->env head ready", "stage-2 issue + hot loads ready", "charge + state machine", "observation stores",
          "rainflow update", "state stores", "reductions + leader", "SEI pass / reset", ]
 d = np.diff(s, axis=1)
-print("cycles per segment, median over the first wave of each workgroup (last step of the run):")
+print("cycles per segment, median over the wavefronts (last step of the run):")
 for k, n in enumerate(names):
     print(f"  {n:34s} {np.median(d[:, k]):8.0f}   p90 {np.percentile(d[:, k], 90):8.0f}")
 tot = s[:, 8] - s[:, 0]
 print(f"  {'total':34s} {np.median(tot):8.0f}   p90 {np.percentile(tot, 90):8.0f}   max {tot.max():8.0f}")
+long = d[:, 7] > 4 * np.median(d[:, 7])
+print(f"wavefronts with a long last segment (burst / daily evaluation / reset): {long.mean() * 100:.1f} %")
+for name, sel in (("ordinary", ~long), ("long", long)):
+    if sel.any():
+        print(f"  {name:9s} last segment median {np.median(d[sel, 7]):8.0f}  p90 {np.percentile(d[sel, 7], 90):8.0f}   total median "
+              f"{np.median(tot[sel]):8.0f}  p90 {np.percentile(tot[sel], 90):8.0f}")
+t0 = s[:, 0].min()
+print("kernel timeline [cycles from the first wave's entry]: last entry", int(s[:, 0].max() - t0), " median exit", int(np.median(s[:, 8]) - t0),
+      " p90 exit", int(np.percentile(s[:, 8], 90) - t0), " last exit", int(s[:, 8].max() - t0))
 print("first wave start spread [cycles]:", int(s[:, 0].max() - s[:, 0].min()), " kernel span:", int(s[:, 8].max() - s[:, 0].min()))
