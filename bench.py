@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched FleetEnv.step() hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: every env of the batch advances one 15-minute slot
-(charge integration, grid balance, arrival/departure state machine, observation, SOC log, daily rainflow/SEI
-degradation, auto-reset), ONE kernel launch per step, inputs (action tape, tables, state) resident in HBM.
-Workload at N=1 = BASELINE.json configs[2]: 4096 envs x 50 EVs, caretaker fleet, load+pv observations, rainflow
-degradation, 48 h episodes, random start rows; synthetic seeded inputs (fleetrl_amd/synth.py).  N>1: every rank runs
-its own 4096-env shard (weak scaling), no data-path collective; one RCCL all-gather of episode returns for logging.
+A "step" is one pass of the hot path over one batch: every env of the batch advances one 15-minute slot (charge
+integration, grid balance, arrival/departure state machine, observation, SOC log, daily degradation, auto-reset), ONE kernel
+launch per step and fleet type, inputs (action tape, tables, state) resident in HBM.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel vs the 8 TB/s HBM roof, algorithmic bytes
-per SURVEY.md section 8d), `cpu_baseline` (the CPU oracle -- a port of the reference's algorithm -- timed on this box's
-host cores on a bounded sample of the same workload), `step_many` (K-steps-per-launch open-loop entry, reported aside).
+Workloads (`--config`, per GPU; synthetic seeded inputs from fleetrl_amd/synth.py):
+  c3 (default)  BASELINE.json configs[2]: 4096 envs x 50 EVs, caretaker fleet, load+pv observations, rainflow/SEI degradation
+  c2            configs[1]: 256 envs x 5 EVs, last-mile delivery, price-only observations, linear degradation
+  c4            configs[3], one GPU's shard (16384 / 8): 2048 envs x 50 EVs, utility fleet, load+pv, rainflow
+  c5            configs[4], one GPU's shard (65536 / 8): 8192 envs x 200 EVs, one third each lmd / ct / ut (own tables and
+                parameters per fleet type = three handles on three HIP streams), spot_2021-like prices, fixed feed-in tariff
+N > 1: every rank runs its own shard of that size (weak scaling), no data-path collective; one RCCL all-gather of episode
+returns for logging, outside the timed region and reported as `log_gather_ms`.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel vs the 8 TB/s HBM roof, algorithmic bytes per
+SURVEY.md section 8d), `cpu_baseline` (the CPU oracle -- a port of the reference's algorithm -- timed on this box's host
+cores on a bounded sample of the same workload), `step_many` (K-steps-per-launch open-loop entry) and `host_path` (the
+host-pointer entry points incl. PCIe, what an SB3 loop sees), both reported aside.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,17 +38,28 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 
+CONFIGS = {
+    "c2": dict(envs=256, evs=5, groups=("lmd",), building=False, pv=False, deg="linear", price_year="2020", feed_in="spot",
+               what="BASELINE.json configs[1]"),
+    "c3": dict(envs=4096, evs=50, groups=("ct",), building=True, pv=True, deg="rainflow", price_year="2020", feed_in="spot",
+               what="BASELINE.json configs[2]"),
+    "c4": dict(envs=2048, evs=50, groups=("ut",), building=True, pv=True, deg="rainflow", price_year="2020", feed_in="spot",
+               what="BASELINE.json configs[3], one GPU's shard of 16384 envs"),
+    "c5": dict(envs=8192, evs=200, groups=("lmd", "ct", "ut"), building=True, pv=True, deg="rainflow", price_year="2021",
+               feed_in="fixed", what="BASELINE.json configs[4], one GPU's shard of 65536 envs"),
+}
 
-def bench_config(num_envs: int, n_evs: int, use_case: str):
-    """The reference's config dict for the benchmark workload (same keys as /root/reference/config.json)."""
+
+def bench_config(num_envs: int, n_evs: int, use_case: str, building: bool = True, pv: bool = True, deg: str = "rainflow"):
+    """The reference's config dict for a benchmark workload (same keys as /root/reference/config.json)."""
     return {
         "data_path": "<synthetic>", "use_case": use_case, "building_name": None, "price_name": None, "tariff_name": None,
-        "schedule_name": None, "pv_name": None, "seed": 0, "include_building": True, "include_pv": True,
+        "schedule_name": None, "pv_name": None, "seed": 0, "include_building": building, "include_pv": pv,
         "include_price": True, "time_picker": "random", "max_batt_cap_in_all_use_cases": 60, "init_soh": 1.0,
-        "log_data": False, "deg_emp": False, "calculate_degradation": True, "verbose": 0, "normalize_in_env": False,
-        "aux": True, "ignore_price_reward": False, "ignore_overloading_penalty": False, "ignore_invalid_penalty": False,
-        "ignore_overcharging_penalty": False, "gen_schedule": False, "gen_start_date": None, "gen_end_date": None,
-        "gen_name": None, "gen_n_evs": n_evs, "spot_markup": None, "spot_mul": None, "feed_in_ded": None,
+        "log_data": False, "deg_emp": deg == "linear", "calculate_degradation": deg != "none", "verbose": 0,
+        "normalize_in_env": False, "aux": True, "ignore_price_reward": False, "ignore_overloading_penalty": False,
+        "ignore_invalid_penalty": False, "ignore_overcharging_penalty": False, "gen_schedule": False, "gen_start_date": None,
+        "gen_end_date": None, "gen_name": None, "gen_n_evs": n_evs, "spot_markup": None, "spot_mul": None, "feed_in_ded": None,
         "real_time": False, "episode_length": 48, "target_soc": 0.85, "obc_max_power": 100, "min_laxity": 2,
     }
 
@@ -55,6 +74,34 @@ def algorithmic_bytes_per_env_step(n_evs: int, obs_dim: int, tail_a: int, rainfl
     b_env = 4.0 * (obs_dim - 7 * n_evs) + 17.0 + 4.0 * (tail_a + 12)
     b_deg = 8.0 * n_evs * ((episode_steps + 1) / 2.0) / 96.0 if rainflow else 0.0
     return n_evs * b_ev + b_env + b_deg
+
+
+def kernel_name(n_evs: int, deg: str) -> str:
+    """The step-kernel instance a launch of this geometry runs (fleet_kernels.hip launch_step_gd)."""
+    g = 1
+    while g < n_evs and g < 64:
+        g <<= 1
+    return (f"fleet_step_kernel<G={g},DEG={deg},MULTI=false,WIDE={'true' if n_evs > 64 else 'false'}>")
+
+
+def kernel_source_sha() -> str:
+    """Identifies the kernel a committed traffic profile was taken on: hash of the kernel sources."""
+    h = hashlib.sha256()
+    for f in ("fleet_kernels.hip", "fleet_device.h"):
+        h.update(open(os.path.join(ROOT, "fleetrl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(config: str, envs: int, evs: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
+    profiles/r02_traffic_<config>.json); None when the profile is absent, was taken on another kernel source or shape."""
+    path = os.path.join(ROOT, "profiles", f"r02_traffic_{config}.json")
+    if not os.path.isfile(path):
+        return None
+    t = json.load(open(path))
+    if t.get("kernel_src_sha") != kernel_source_sha() or (t.get("envs"), t.get("evs")) != (envs, evs):
+        return None
+    return t.get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(params, tables, time_feat, n_evs: int, budget_s: float = 8.0):
@@ -86,18 +133,57 @@ def cpu_baseline(params, tables, time_feat, n_evs: int, budget_s: float = 8.0):
         eng.close()
         return num_envs * steps / dt, steps, dt
 
-    v1, steps1, dt1 = run(128, 1, budget_s)
+    e1 = max(1, min(128, 6400 // n_evs))
+    v1, steps1, dt1 = run(e1, 1, budget_s)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     nthr = max(1, min(avail, 32))
-    vm, stepsm, dtm = run(2048, nthr, budget_s)
+    em = max(nthr, min(2048, 102400 // n_evs))
+    vm, stepsm, dtm = run(em, nthr, budget_s)
     return {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"128 envs x {n_evs} EVs x {steps1} steps in {dt1:.1f} s on one core, same tables/params/action "
+            "sample": f"{e1} envs x {n_evs} EVs x {steps1} steps in {dt1:.1f} s on one core, same tables/params/action "
                       f"distribution as the GPU run",
             "all_cores": {"value": vm, "cores": nthr, "host_cpus": avail,
-                          "sample": f"2048 envs x {n_evs} EVs x {stepsm} steps in {dtm:.1f} s, OpenMP over envs"}}
+                          "sample": f"{em} envs x {n_evs} EVs x {stepsm} steps in {dtm:.1f} s, OpenMP over envs"}}
+
+
+class Group:
+    """One fleet type of the workload: a handle of the C ABI (own HIP stream) with its device-resident action tape and
+    output slices."""
+
+    def __init__(self, torch, dev, use_case, envs, evs, spec, rank, env_id_offset, tape_len, seed):
+        from fleetrl_amd.batch import FleetBatch
+        from fleetrl_amd.config import resolve_config
+        from fleetrl_amd.params import make_params, time_features
+        from fleetrl_amd.synth import synth_tables
+
+        self.use_case, self.E, self.N = use_case, envs, evs
+        cfg = bench_config(envs, evs, use_case, spec["building"], spec["pv"], spec["deg"])
+        self.rc = resolve_config(cfg)
+        self.tables = synth_tables(use_case, evs, seed=1234, include_building=spec["building"], include_pv=spec["pv"],
+                                   price_year=spec["price_year"], feed_in=spec["feed_in"])
+        self.tf = time_features(self.tables)
+        self.params = make_params(self.rc, self.tables, envs, auto_reset=True, env_id_offset=env_id_offset, seed=0)
+        self.batch = FleetBatch(self.params, self.tables, self.tf, device=dev.index)
+        # device-resident action tape: uniform(-1,1) float32, 15 % forced to 0 (SURVEY.md section 8d), seeded per rank / group
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        self.L = tape_len
+        self.tape = torch.rand((tape_len, envs, evs), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+        self.tape[torch.rand((tape_len, envs, evs), device=dev, generator=gen) < 0.15] = 0.0
+        self.obs = torch.empty((envs, self.batch.obs_dim), device=dev, dtype=torch.float32)
+        self.reward = torch.empty(envs, device=dev, dtype=torch.float64)
+        self.done = torch.empty(envs, device=dev, dtype=torch.uint8)
+        S = self.rc.episode_length * (60 // self.rc.minutes)
+        tail_a = 2 * (self.rc.price_lookahead + 1) + (self.rc.bl_pv_lookahead + 1) * (int(spec["building"]) + int(spec["pv"]))
+        self.rainflow = spec["deg"] == "rainflow"
+        self.bytes_step = algorithmic_bytes_per_env_step(evs, self.batch.obs_dim, tail_a, self.rainflow, S)
+
+    def run(self, k, use_graph):
+        self.batch.run_tape_dev(k, self.tape.data_ptr(), self.L, self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                use_graph=use_graph)
 
 
 def main():
@@ -105,29 +191,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--evs", type=int, default=50)
-    ap.add_argument("--use-case", default="ct")
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json workload (per GPU), see the module docstring")
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="override the config's batch size")
+    ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
+    ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--tape-len", type=int, default=64)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with --device-index) only exists to smoke-test the multi-rank control "
                          "flow with several ranks on ONE GPU, which RCCL refuses")
     ap.add_argument("--device-index", type=int, default=None, help="GPU to use instead of LOCAL_RANK (test hook, see --backend)")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
-    ap.add_argument("--deg", default="rainflow", choices=["none", "linear", "rainflow"],
-                    help="degradation model (default rainflow = the BASELINE workload; others are diagnostics)")
+    ap.add_argument("--deg", default=None, choices=["none", "linear", "rainflow"],
+                    help="override the config's degradation model (diagnostics)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    from fleetrl_amd.batch import FleetBatch
-    from fleetrl_amd.config import resolve_config
-    from fleetrl_amd.distributed import dist_env, gather_episode_stats
-    from fleetrl_amd.params import make_params, time_features
-    from fleetrl_amd.synth import synth_tables
+    from fleetrl_amd.distributed import dist_env, gather_episode_stats, shard_range
 
     rank, local_rank, world = dist_env()
     if world != args.gpus:
@@ -145,40 +229,41 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    E, N = args.envs_per_gpu, args.evs
-    cfg = bench_config(E, N, args.use_case)
-    cfg["calculate_degradation"] = args.deg != "none"
-    cfg["deg_emp"] = args.deg == "linear"
-    rc = resolve_config(cfg)
-    tables = synth_tables(args.use_case, N, seed=1234)
-    tf = time_features(tables)
-    params = make_params(rc, tables, E, auto_reset=True, env_id_offset=rank * E, seed=0)
-    batch = FleetBatch(params, tables, tf, device=local_rank)
-
-    # device-resident action tape: uniform(-1,1) float32, 15 % forced to 0, seeded per rank
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    L = args.tape_len
-    tape = torch.rand((L, E, N), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-    tape[torch.rand((L, E, N), device=dev, generator=gen) < 0.15] = 0.0
-    obs = torch.empty((E, batch.obs_dim), device=dev, dtype=torch.float32)
-    reward = torch.empty(E, device=dev, dtype=torch.float64)
-    done = torch.empty(E, device=dev, dtype=torch.uint8)
-    torch.cuda.synchronize()
+    spec = dict(CONFIGS[args.config])
+    if args.deg:
+        spec["deg"] = args.deg
+    if args.use_case:
+        spec["groups"] = (args.use_case,)
+    E = args.envs_per_gpu or spec["envs"]
+    N = args.evs or spec["evs"]
+    # a graph replays tape_len launches; a run shorter than that replays a graph of its own length
+    L = max(1, min(args.tape_len, args.steps))
     use_graph = not args.no_graph
+    groups, off = [], 0
+    for k, uc in enumerate(spec["groups"]):
+        lo, hi = shard_range(E, len(spec["groups"]), k)  # env groups in order: the first E % n groups hold one env more
+        groups.append(Group(torch, dev, uc, hi - lo, N, spec, rank, rank * E + off, L, 1 + rank * 16 + k))
+        off += hi - lo
+    torch.cuda.synchronize()
 
     def run(k):
-        batch.run_tape_dev(k, tape.data_ptr(), L, obs.data_ptr(), reward.data_ptr(), done.data_ptr(), use_graph=use_graph)
+        for g in groups:  # asynchronous, one stream per group: the groups' kernels overlap
+            g.run(k, use_graph)
 
-    batch.reset_dev(obs.data_ptr())
+    def sync():
+        for g in groups:
+            g.batch.synchronize()
+
+    for g in groups:
+        g.batch.reset_dev(g.obs.data_ptr())
     # clock ramp: replay the same step (untimed) for a fixed wall time before the W warmup steps, so that a short
     # --steps/--warmup run measures the same steady state as a long one
     t_prime = time.perf_counter()
     while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
-        run(256)
-        batch.synchronize()
+        run(4 * L)
+        sync()
     run(args.warmup)
-    batch.synchronize()
+    sync()
     ret = torch.zeros(E, device=dev, dtype=torch.float64)
     ln = torch.zeros(E, device=dev, dtype=torch.int32)
     gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
@@ -189,53 +274,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: exactly K steps between two barriers -----------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    batch.timer_start()
+    for g in groups:
+        g.batch.timer_start()
     run(args.steps)
-    ev_ms = batch.timer_stop()  # HIP events on the stream the kernels run on
-    # logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1)
-    batch.get_dev("last_ep_return", ret.data_ptr())  # device-side unpack, no host round trip
-    batch.get_dev("last_ep_len", ln.data_ptr())
-    batch.synchronize()
-    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
+    for g in groups:
+        g.batch.timer_mark()
+    ev_ms = [g.batch.timer_read() for g in groups]  # HIP events on the streams the kernels run on (each read waits for its stream)
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
         w = torch.tensor([wall], device=cdev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
-    batch.check_errors()
+    # ---- logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1) ------------------
+    t1 = time.perf_counter()
+    off = 0
+    for g in groups:
+        g.batch.get_dev("last_ep_return", ret[off:off + g.E].data_ptr())  # device-side unpack, no host round trip
+        g.batch.get_dev("last_ep_len", ln[off:off + g.E].data_ptr())
+        off += g.E
+    sync()
+    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
+    barrier()
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    for g in groups:
+        g.batch.check_errors()
 
     out = None
     if rank == 0:
-        S = rc.episode_length * (60 // rc.minutes)
-        tail_a = 2 * (rc.price_lookahead + 1) + 2 * (rc.bl_pv_lookahead + 1)
-        bytes_step = algorithmic_bytes_per_env_step(N, batch.obs_dim, tail_a, True, S)
-        # dominant kernel: fleet_step_kernel, one launch per step; per-launch duration from one HIP event pair per launch
-        # average launch duration: HIP events on the kernels' stream around the timed region (K graph-replayed launches,
-        # ~0.5 us of inter-kernel gap per launch included -> slightly conservative; rocprofv3's per-kernel average is in
-        # profiles/).  A second figure brackets every launch with its own event pair (adds ~1.5 us of event overhead).
-        k_ms = ev_ms / args.steps
-        per = batch.time_steps_dev(min(args.steps, 512), tape.data_ptr(), L, obs.data_ptr(), reward.data_ptr(), done.data_ptr())
-        achieved = bytes_step * E / (k_ms * 1e-3) / 1e9
+        # dominant kernel: fleet_step_kernel, one launch per step and group.  Average launch duration: HIP events on the
+        # kernels' streams around the timed region (graph-replayed launches, ~0.5 us of inter-kernel gap per launch included
+        # -> slightly conservative; rocprofv3's per-kernel average is in profiles/).  With several groups their streams run
+        # concurrently: the launch "duration" is the slowest stream's time per step, and the bytes are all groups' bytes.
+        k_ms = max(ev_ms) / args.steps
+        bytes_launch = sum(g.bytes_step * g.E for g in groups)
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        g0 = max(groups, key=lambda g: g.E * g.N)
+        per = g0.batch.time_steps_dev(min(args.steps, 512), g0.tape.data_ptr(), g0.L, g0.obs.data_ptr(), g0.reward.data_ptr(), g0.done.data_ptr())
         # K-steps-per-launch entry (open-loop rollouts), reported aside
-        K = 64
-        rsum = torch.empty(E, device=dev, dtype=torch.float64)
-        batch.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rsum.data_ptr())
-        batch.synchronize()
-        batch.timer_start()
+        K = min(64, L)
+        rsum = torch.empty(g0.E, device=dev, dtype=torch.float64)
+        g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
+        g0.batch.synchronize()
+        g0.batch.timer_start()
         reps = max(1, min(args.steps, 2048) // K)
         for _ in range(reps):
-            batch.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rsum.data_ptr())
-        many_ms = batch.timer_stop()
-        batch.check_errors()
-        # HBM traffic of the step kernel from the committed rocprofv3 PMC passes of this same command
-        # (tools/prof_traffic.sh -> profiles/r01_traffic_step_kernel.json); null when the workload differs from the profiled one
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_step_kernel.json")
-        if os.path.isfile(tpath) and (E, N, args.use_case, args.deg) == (4096, 50, "ct", "rainflow"):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
+        many_ms = g0.batch.timer_stop()
+        g0.batch.check_errors()
+        fleets = "+".join(g.use_case for g in groups)
+        graph_used = use_graph and args.steps >= L
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -244,29 +335,54 @@ def main():
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{E} envs x {N} EVs per GPU, {args.use_case} fleet, load+pv obs, rainflow/SEI degradation, "
-                                   f"48 h episodes, random start rows, auto-reset (BASELINE.json configs[2])",
-                       "envs_per_gpu": E, "evs_per_env": N, "obs_dim": batch.obs_dim, "launch": "hipGraph" if use_graph else "eager", "prime_ms": args.prime_ms,
+            "config": {"workload": f"{E} envs x {N} EVs per GPU, {fleets} fleet{'s (one third each)' if len(groups) > 1 else ''}, "
+                                   f"{'load+pv' if spec['building'] and spec['pv'] else 'price-only'} obs, {spec['deg']} degradation, "
+                                   f"{'spot_2021-like prices + fixed feed-in tariff, ' if spec['price_year'] == '2021' else ''}"
+                                   f"48 h episodes, random start rows, auto-reset ({spec['what']})",
+                       "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
+                       "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
+                       "launch": (f"hipGraph of {L} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_env_step": bytes_step, "bytes_per_launch": bytes_step * E,
+                         "traffic": committed_traffic(args.config, E, N) if not (args.deg or args.use_case) else None,
+                         "kernel": kernel_name(N, spec["deg"]), "kernel_ms": k_ms,
+                         "kernel_src_sha": kernel_source_sha(),
+                         "algorithmic_bytes_per_env_step": bytes_launch / E, "bytes_per_launch": bytes_launch,
                          "kernel_ms_event_pair_per_launch": float(np.mean(per))},
             # K steps per launch: only the last step's observation is part of the result (and written), so the
             # algorithmic bytes per env-step are smaller by the observation row for K-1 of the K steps
-            "step_many": {"K": K, "env_steps_per_s": E * K * reps / (many_ms * 1e-3),
-                          "algorithmic_bytes_per_env_step": bytes_step - 4 * batch.obs_dim * (K - 1) / K,
-                          "GBps": (bytes_step - 4 * batch.obs_dim * (K - 1) / K) * E * K * reps / (many_ms * 1e-3) / 1e9},
+            "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * reps / (many_ms * 1e-3),
+                          "algorithmic_bytes_per_env_step": g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K,
+                          "GBps": (g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K) * g0.E * K * reps / (many_ms * 1e-3) / 1e9},
+            "log_gather_ms": gather_ms,
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
+        if not args.no_host_path and world == 1:
+            out["host_path"] = host_path(g0, groups)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run item (the other ranks would idle)
-            out["cpu_baseline"] = cpu_baseline(params, tables, tf, N)
-    batch.close()
+            out["cpu_baseline"] = cpu_baseline(g0.params, g0.tables, g0.tf, N)
+    for g in groups:
+        g.batch.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def host_path(g0, groups, budget_s: float = 1.5):
+    """The host-pointer path, PCIe both ways, as an SB3 loop sees it (never the headline value): `fleet_step_host` through
+    FleetBatch.step with NumPy buffers, bounded to about a second."""
+    acts = g0.tape[:8].cpu().numpy()
+    g0.batch.step(acts[0])
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        g0.batch.step(acts[n % 8])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"env_steps_per_s": g0.E * n / dt, "ms_per_step": dt * 1e3 / n, "envs": g0.E,
+            "what": "fleet_step_host: actions host->device, one launch, observations/rewards/dones device->host, synchronous"}
 
 
 if __name__ == "__main__":

@@ -138,18 +138,26 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.isfile(path):
-        # not built yet (fresh checkout): compile it now if the ROCm toolchain is here -- still the HIP library, never a
-        # substitute for it
-        try:
-            from . import build as _build
+    # not built yet (fresh checkout) or older than its sources: compile it now if the ROCm toolchain is here -- still the HIP
+    # library, never a substitute for it.  Without hipcc an existing library is used as it is.
+    why = ""
+    try:
+        from . import build as _build
 
+        have_hipcc = True
+        try:
+            _build.hipcc()
+        except RuntimeError:
+            have_hipcc = False
+        if have_hipcc and _build.needs_build():
             _build.build()
-        except Exception:  # no hipcc / compile error: report the missing library below
-            pass
+    except Exception as exc:  # compile error: say so instead of reporting a merely "missing" library
+        why = f"  Building it failed: {exc}"
+        if os.path.isfile(path):
+            raise FleetHipError(ERR_INVALID, f"{path} is older than its sources and rebuilding it failed: {exc}") from exc
     if not os.path.isfile(path):
         raise FleetHipError(ERR_NODEVICE, f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
-                                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+                                          f"(hipcc --offload-arch=gfx950).  There is no CPU fallback.{why}")
     # One HIP runtime per process: PyTorch bundles its own libamdhip64 and only finds the GPU if that copy is the one
     # that gets loaded; loading this library first would pull in /opt/rocm's copy instead ("No HIP GPUs are available"
     # on the first torch.cuda call afterwards).  Importing torch first makes the order deterministic.
@@ -185,13 +193,15 @@ def load_library():
     lib.fleet_check_errors.argtypes = [vp]
     lib.fleet_timer_start.argtypes = [vp]
     lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.fleet_timer_mark.argtypes = [vp]
+    lib.fleet_timer_read.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_log_capacity", "fleet_log_read",
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
-                 "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev"):
+                 "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -203,5 +213,5 @@ EXPORTED_SYMBOLS = (
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev",
     "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
-    "fleet_timer_stop", "fleet_run_tape_dev", "fleet_time_steps_dev",
+    "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
 )

@@ -175,6 +175,14 @@ class FleetBatch:
         self._check(self.lib.fleet_timer_stop(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def timer_mark(self):
+        self._check(self.lib.fleet_timer_mark(self.h))
+
+    def timer_read(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.fleet_timer_read(self.h, C.byref(ms)))
+        return float(ms.value)
+
     # ---- state access ----------------------------------------------------------------------------------------
     def get(self, name: str) -> np.ndarray:
         fid, dtype, per_car = _capi.FIELDS[name]

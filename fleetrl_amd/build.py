@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ("fleet_kernels.hip", "fleet_capi.hip")
-HEADERS = ("fleet_device.h", os.path.join("..", "..", "include", "fleet_hip.h"))
+HEADERS = ("fleet_device.h", os.path.join("..", "..", "include", "fleet_hip.h"))  # relative to csrc/
 # -ffp-contract=off: no fused multiply-add contraction, so float64 results follow the reference's operation
 # order bit for bit on the SOC path.  No -ffast-math for the same reason.
 # -mllvm -disable-machine-licm: the machine-level loop-invariant code motion hoists every rare path's constant
@@ -40,16 +40,34 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libfleet_hip.so if it is missing or older than its sources.  Safe under `torch.distributed.run`: the ranks
+    serialise on a lock file, the first one compiles into a temporary file in the same directory and renames it into place
+    (a rank never maps a half-written library), the others find the fresh library when they get the lock."""
+    import fcntl
+    import tempfile
+
     if not force and not needs_build():
         return lib_path()
     csrc = os.path.join(_HERE, "csrc")
     extra = os.environ.get("FLEET_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics only (ablation builds)
-    cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(csrc, s) for s in SOURCES], "-o", lib_path()]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
-    if verbose:
-        print(" ".join(cmd))
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while this one waited
+                return lib_path()
+            fd, tmp = tempfile.mkstemp(prefix=".libfleet_hip.", suffix=".so.tmp", dir=_HERE)
+            os.close(fd)
+            cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                os.unlink(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+            os.chmod(tmp, 0o755)
+            os.replace(tmp, lib_path())
+            if verbose:
+                print(" ".join(cmd))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return lib_path()
 
 

@@ -757,6 +757,19 @@ int fleet_timer_stop(fleet_handle h, float* elapsed_ms) {
   return FLEET_OK;
 }
 
+int fleet_timer_mark(fleet_handle h) {
+  if (!h) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipEventRecord(h->ev_stop, h->stream));
+  return FLEET_OK;
+}
+
+int fleet_timer_read(fleet_handle h, float* elapsed_ms) {
+  if (!h || !elapsed_ms) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipEventSynchronize(h->ev_stop));
+  HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+  return FLEET_OK;
+}
+
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                        double* reward, uint8_t* done, int use_graph) {
   if (!h || steps < 0 || !tape || tape_len < 1 || !obs || !reward || !done ||

@@ -462,8 +462,9 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
 // `lp`: the env's data-log cursor (rows written so far; only used when the log is on), advanced by the row reset() writes.
-template <int G>
+template <int G, bool LOG>
 __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
+  const bool log_on = LOG && (d.log_pos != nullptr);
   const int N = d.N;
   const size_t EN = (size_t)d.E * N;
   const FleetCold* cd = d.cold;
@@ -472,8 +473,8 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
   r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
   // data log: the row reset() writes -- time, observation and SoH, zeros for everything else (:420-432)
-  const size_t lrow = d.log_pos ? (size_t)(lp % d.log_cap) * d.E + e : 0;
-  float* const log_obs_row = d.log_pos ? d.log_obs + lrow * d.obs_dim : nullptr;
+  const size_t lrow = log_on ? (size_t)(lp % d.log_cap) * d.E + e : 0;
+  float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
   for (int c = g; c < N; c += G) {
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
     const TabX tx = d.tab[ti];
@@ -511,7 +512,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       row[4] = soc_deg;
     }
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
-    if (d.log_pos) {
+    if (log_on) {
       write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb, ar);
       double* lev = d.log_ev + lrow * 4 * N + c;
       lev[0] = 0.0;
@@ -521,7 +522,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     }
   }
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
-  if (d.log_pos) {
+  if (log_on) {
     write_obs_tail<G>(d, log_obs_row, start, g);
     if (leader) {
       d.log_row[lrow] = (int32_t)((uint32_t)start | 0x80000000u);
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
   if (d.env[e].ep_len > 0 && d.env[e].start_done >= 0) r.episodes += 1;
   int lp = d.log_pos ? d.log_pos[e] : 0;
-  reset_env<G>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
+  reset_env<G, true>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG, bool MULTI, bool WIDE>
+template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false>
 __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py): what the first loads of a wavefront need -- its env record, its lanes' state records and action
@@ -640,8 +641,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     if (G == 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
   }
 
-  // data log cursor of the env (rows written so far), carried in a register over the launch's steps
-  int lp = d.log_pos ? d.log_pos[e] : 0;
+  // data log cursor of the env (rows written so far), carried in a register over the launch's steps.  The logging code lives
+  // in an instance of its own (LOG, multi-step form; the launcher routes every launch of a logging batch to it), so the
+  // kernels of the hot path pay nothing for it -- neither instructions nor registers.
+  static_assert(!LOG || MULTI, "the data log is compiled into the multi-step kernel only");
+  constexpr bool log_on = LOG;
+  int lp = log_on ? d.log_pos[e] : 0;
   if (G == 64) lp = __builtin_amdgcn_readfirstlane(lp);
 
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
     // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
     // buffer, so K-step launches log every step although they only return the last observation
-    const bool logs = d.log_pos && env_ok && !is_done;
+    const bool logs = log_on && env_ok && !is_done;
     const size_t lrow = logs ? (size_t)(lp % d.log_cap) * d.E + e : 0;
     float* const log_obs_row = logs ? d.log_obs + lrow * d.obs_dim : nullptr;
 
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     asum = group_sum_to_last<G>(asum);
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
 #endif
-    if (d.log_pos) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
+    if (log_on) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
       penalty_record += penrec;
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       r.episodes += 1;
       if (resets) {
         if (env_ok) {
-          reset_env<G>(*d.self, e, g, leader, r, obs_row, lp);
+          reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;
@@ -985,10 +990,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     er->ep_return = ep_return;
     er->ep_len = ep_len;
     er->penalty_record = penalty_record;
-    if (d.log_pos) d.log_pos[e] = lp;
+    if (log_on) d.log_pos[e] = lp;
     if (MULTI) {
       reward[e] = rt ? last_rew : reward_sum;
-      if (rt && done) done[e] = last_done ? 1 : 0;
+      if (done && (rt || steps == 1)) done[e] = (rt ? last_done : (n_done != 0)) ? 1 : 0;  // one agent step: its done flag
       if (done_count) done_count[e] = n_done;
       if (act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
@@ -1058,10 +1063,14 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
 #define FLEET_PRE_ARGS d.env, d.hot, d.soh, d.rf_top, actions, d.E, d.N,  /* the preloaded leading arguments */
-  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time);
+  // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
+  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,
+                         done, terminal_obs, done_count);
+    else if (d.log_pos)
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64), true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
     else
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
@@ -1069,6 +1078,9 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   } else {
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
+                         terminal_obs, done_count);
+    else if (d.log_pos)
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
                          terminal_obs, done_count);
     else
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,

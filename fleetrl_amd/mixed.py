@@ -53,6 +53,7 @@ class FleetMixedVecEnv:
             yield core, off, off + core.num_envs
 
     def reset(self):
+        self._torch.cuda.current_stream().synchronize()  # the buffers' fills ran on torch's stream, the handles have their own
         for core, lo, hi in self._slices():
             core.batch.reset_dev(self._obs[lo:hi].data_ptr())
         for core in self.cores:

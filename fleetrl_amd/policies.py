@@ -60,6 +60,7 @@ def run_policy(batch, policy, steps: int, *, chunk: int = 96, night=None):
     if night is not None:
         batch.set_night_policy(*night)
     dev = torch.device("cuda", batch.device)
+    batch.use_torch_stream(dev)  # launches and the torch accumulations below on ONE stream: ordered without host round trips
     E = batch.E
     obs = torch.zeros((E, batch.obs_dim), device=dev, dtype=torch.float32)
     rsum = torch.zeros(E, device=dev, dtype=torch.float64)
@@ -70,7 +71,6 @@ def run_policy(batch, policy, steps: int, *, chunk: int = 96, night=None):
     while left > 0:
         k = min(left, int(chunk))
         batch.rollout_policy_dev(pol, k, obs.data_ptr(), rsum.data_ptr(), dcnt.data_ptr())
-        batch.synchronize()  # the handle's stream is not torch's: order the accumulation after the launch
         rtot += rsum
         dtot += dcnt
         left -= k

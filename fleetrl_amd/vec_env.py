@@ -238,10 +238,17 @@ class FleetVecEnv:
     # -- zero-copy path for torch policies living on the same GPU ------------------------------------------
     def step_torch(self, actions, obs_out=None, reward_out=None, done_out=None, terminal_out=None):
         """actions: float32 CUDA tensor [num_envs, num_cars] -> (obs f32 [E,obs_dim], reward f64 [E], done u8 [E]) on the
-        GPU, asynchronous on the batch's stream (call `self.core.batch.synchronize()` or share the stream)."""
+        GPU, asynchronous on torch's current stream (the handle adopts it: ordered after the ops that produced `actions`, and
+        ops enqueued afterwards see the outputs)."""
         import torch
 
         dev = actions.device
+        # the handle must launch on the stream that produced `actions` and will consume the outputs: its own stream is
+        # non-blocking, i.e. not ordered with torch's
+        cur = torch.cuda.current_stream(dev).cuda_stream
+        if getattr(self, "_torch_stream", None) != cur:
+            self.core.batch.set_stream(cur)
+            self._torch_stream = cur
         E, D = self.num_envs, self.core.obs_dim
         a = actions.contiguous()
         dt = _capi.ACT_F64 if a.dtype == torch.float64 else _capi.ACT_F32

@@ -268,6 +268,10 @@ int fleet_check_errors(fleet_handle h);
 /* ---- measurement helpers (bench.py): HIP events on the handle's stream ------------------------------- */
 int fleet_timer_start(fleet_handle h);
 int fleet_timer_stop(fleet_handle h, float* elapsed_ms);  /* synchronises on the stop event */
+/* the same in two halves, for several handles whose streams run concurrently: record every handle's stop event first
+ * (asynchronous), then read them (each read synchronises on its own stop event) */
+int fleet_timer_mark(fleet_handle h);
+int fleet_timer_read(fleet_handle h, float* elapsed_ms);
 /* launch `steps` single-step launches back to back from a device-resident action tape [tape_len,E,N]
  * (step i uses tape row i % tape_len); optionally through a captured hipGraph. */
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,

@@ -33,3 +33,34 @@ def test_committed_traffic_profile_is_well_formed():
     t = json.load(open(path))
     assert t["hbm_bytes_per_launch"] == t["hbm_read_bytes_per_launch"] + t["hbm_write_bytes_per_launch"]
     assert t["hbm_read_bytes_per_launch"] == t["FETCH_SIZE"] * 1024 * 2  # gfx950 read-side correction
+
+
+def test_kernel_name_follows_the_launcher():
+    assert bench.kernel_name(50, "rainflow") == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
+    assert bench.kernel_name(200, "rainflow") == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=true>"
+    assert bench.kernel_name(5, "linear") == "fleet_step_kernel<G=8,DEG=linear,MULTI=false,WIDE=false>"
+
+
+def test_committed_traffic_only_counts_for_the_kernel_it_was_profiled_on(tmp_path, monkeypatch):
+    """`roofline.traffic` is null unless the committed profile carries the hash of the current kernel sources and the
+    shape of the run."""
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.makedirs(tmp_path / "fleetrl_amd" / "csrc")
+    for f in ("fleet_kernels.hip", "fleet_device.h"):
+        (tmp_path / "fleetrl_amd" / "csrc" / f).write_text("v1 " + f)
+    sha = bench.kernel_source_sha()
+    (tmp_path / "profiles" / "r02_traffic_c3.json").write_text(json.dumps(
+        {"kernel_src_sha": sha, "envs": 4096, "evs": 50, "hbm_bytes_per_launch": 123.0}))
+    assert bench.committed_traffic("c3", 4096, 50) == 123.0
+    assert bench.committed_traffic("c3", 16384, 50) is None
+    assert bench.committed_traffic("c5", 8192, 200) is None
+    (tmp_path / "fleetrl_amd" / "csrc" / "fleet_kernels.hip").write_text("v2")
+    assert bench.committed_traffic("c3", 4096, 50) is None
+
+
+def test_every_baseline_config_has_a_bench_mode():
+    assert set(bench.CONFIGS) == {"c2", "c3", "c4", "c5"}
+    assert bench.CONFIGS["c3"]["envs"] == 4096 and bench.CONFIGS["c3"]["evs"] == 50
+    assert bench.CONFIGS["c5"]["groups"] == ("lmd", "ct", "ut") and bench.CONFIGS["c5"]["envs"] * 8 == 65536
+    assert bench.CONFIGS["c4"]["envs"] * 8 == 16384 and bench.CONFIGS["c2"]["deg"] == "linear"
