@@ -1,0 +1,54 @@
+"""bench.py end to end on the GPU box: the JSON contract at N = 1, and the N = 2 control flow (sharding by rank, barriers,
+max-over-ranks timing, the logging all-gather) with two ranks sharing ONE GPU over gloo -- RCCL refuses two ranks on one
+device, and the pool has no multi-GPU box for the builder; the RCCL path itself is `--backend nccl` (default) and differs
+only in where the gathered tensors live."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_single_gpu():
+    res = subprocess.run([sys.executable, "bench.py", "--steps", "300", "--warmup", "20", "--envs-per-gpu", "512", "--prime-ms", "50"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = _json_line(res.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 300 and d["unit"] == "env-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel"] == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
+    assert abs(d["value"] - 512 * 300 / (d["ms_per_step"] * 300 * 1e-3)) / d["value"] < 1e-9
+    assert d["config"]["launch"] == "hipGraph of 64 launches"
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert d["episodes_gathered"] == 512
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "400", "--warmup", "50", "--envs-per-gpu", "768",
+           "--backend", "gloo", "--device-index", "0", "--prime-ms", "50"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)  # the launcher itself never touches the GPU
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 768
+    assert d["episodes_gathered"] == 2 * 768  # both ranks' finished episodes arrived through the gather
+    assert abs(d["value"] - 2 * 768 * 400 / (d["ms_per_step"] * 400 * 1e-3)) / d["value"] < 1e-9  # whole-job aggregate
+    assert "cpu_baseline" not in d and "host_path" not in d  # single-GPU-run items

@@ -164,6 +164,57 @@ def test_c5_shard_size_full_batch():
     _compare("lmd", 200, 8192, "rainflow", False, steps=100, seed=22)
 
 
+def test_c5_mixed_shard_full_batch():
+    """BASELINE.json configs[4] as it is written -- one GPU's shard of 8192 envs x 200 EVs with one third each of last-mile,
+    caretaker and utility fleets (own tables / parameters per type, three handles on three streams behind
+    `FleetMixedVecEnv`), spot_2021-like prices and a fixed feed-in tariff that is NOT the spot price -- against three CPU
+    oracles with the same env-id offsets, over an episode end (24 h episodes, 110 steps)."""
+    from fleetrl_amd import FleetMixedVecEnv
+    from fleetrl_amd.distributed import shard_range
+    from oracle.fleet_oracle import OracleBatch
+
+    E, N, steps = 8192, 200, 110
+    groups = []
+    for k, uc in enumerate(("lmd", "ct", "ut")):
+        lo, hi = shard_range(E, 3, k)
+        tb = synth_tables(uc, N, seed=300 + k, price_year="2021", feed_in="fixed")
+        assert not np.array_equal(tb.tariff, tb.delu)
+        groups.append((_cfg(uc, "rainflow", False), hi - lo, dict(tables=tb, seed=7)))
+    mixed = FleetMixedVecEnv(groups)
+    assert mixed.num_envs == E and mixed.obs_dim == 7 * N + 38
+    cpus = [OracleBatch(c.params, c.tables, time_features(c.tables), threads=32) for c in mixed.cores]
+    assert [int(c.params.env_id_offset) for c in mixed.cores] == [0, 2731, 5462]
+    obs = mixed.reset()
+    np.testing.assert_array_equal(obs, np.concatenate([c.reset() for c in cpus]))
+    rng = np.random.default_rng(31)
+    n_done = 0
+    for s in range(steps):
+        a = rng.uniform(-1, 1, size=(E, N)).astype(np.float32)
+        a[rng.random(a.shape) < 0.15] = 0.0
+        o, r, d, infos = mixed.step(a)
+        lo = 0
+        for c in cpus:
+            oc, rc_, dc, tc = c.step(a[lo:lo + c.E])
+            np.testing.assert_array_equal(d[lo:lo + c.E], dc.astype(bool), err_msg=f"done, step {s}")
+            np.testing.assert_allclose(o[lo:lo + c.E], oc, rtol=1e-5, atol=1e-6, err_msg=f"obs, step {s}")
+            np.testing.assert_allclose(r[lo:lo + c.E], rc_, rtol=1e-5, atol=1e-4, err_msg=f"reward (float32 in the VecEnv), step {s}")
+            for i in np.nonzero(dc)[0][:8]:
+                np.testing.assert_allclose(infos[lo + i]["terminal_observation"], tc[i], rtol=1e-5, atol=1e-6)
+            lo += c.E
+        n_done += int(d.sum())
+    assert n_done >= E  # every env went through an auto-reset
+    for core, c in zip(mixed.cores, cpus):
+        core.batch.check_errors()
+        np.testing.assert_array_equal(core.batch.get("time_idx"), c.get("time_idx"))
+        np.testing.assert_allclose(core.batch.get("soc"), c.get("soc"), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(core.batch.get("soh"), c.get("soh"), rtol=1e-9)
+        np.testing.assert_array_equal(core.batch.get("rf_len"), c.get("rf_len"))
+        np.testing.assert_allclose(core.batch.get("cashflow"), c.get("cashflow"), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(core.batch.get("last_ep_return"), c.get("last_ep_return"), rtol=1e-9, atol=1e-8)
+        c.close()
+    mixed.close()
+
+
 def test_c4_shard_size_full_batch():
     """BASELINE.json configs[3], one GPU's shard at full size: 2048 envs x 50 EVs, utility fleet, normalised observations."""
     _compare("ut", 50, 2048, "rainflow", True, steps=200, seed=23)

@@ -152,3 +152,63 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in text and "import oracle" not in text and "fleet_oracle" not in text, f
+
+
+def _create_status(p, tables, time_feat):
+    """fleet_create's argument check runs before the device is touched, so what it rejects can be tested without a GPU."""
+    lib = _capi.load_library()
+    tc, keep = _capi.pack_tables(tables, time_feat)
+    h = ctypes.c_void_p()
+    rc = lib.fleet_create(ctypes.byref(p), ctypes.byref(tc), 0, ctypes.byref(h))
+    msg = lib.fleet_last_error(None).decode()
+    if rc == _capi.OK:
+        lib.fleet_destroy(h)
+    del keep
+    return rc, msg
+
+
+def test_create_rejects_episodes_longer_than_the_packed_stack_indices():
+    """The rainflow stack indices travel in 13-bit fields of the hot record: an episode of more than 8188 steps (85 days at
+    15 min) would overflow them silently -- rejected by fleet_create and, with a clear message, by the config layer."""
+    g = load_trace("ct5_both_rainflow")
+    p = params_for(g)
+    p.episode_steps = 8189
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc == _capi.ERR_INVALID and "8191" in msg
+    p.deg_mode = _capi.DEG_LINEAR  # no stack: any length goes (the status then only depends on the device)
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc != _capi.ERR_INVALID
+    cfg = dict(g.cfg)
+    cfg["episode_length"] = 24 * 90
+    with pytest.raises(ValueError, match="8188"):
+        validate_supported(resolve_config(cfg))
+
+
+def test_create_range_checks_the_irregular_grid_tables():
+    """finish_row / lookahead_row entries index the tables on the host (tail rows) and on the device: out-of-range entries
+    are rejected instead of read."""
+    from golden_util import load_rt_trace
+
+    g = load_rt_trace("lmd1_both_irregular")
+    irr = g.tables.meta.get("irregular")
+    p = params_for(g)
+    assert g.tables.meta.get("irregular") is not None
+    rc, _ = _create_status(p, g.tables, g.time_feat)
+    assert rc != _capi.ERR_INVALID
+    keep = g.tables.meta["irregular"]["finish_row"].copy()
+    g.tables.meta["irregular"]["finish_row"][3] = g.tables.T + 7
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc == _capi.ERR_INVALID and "finish_row" in msg
+    g.tables.meta["irregular"]["finish_row"][:] = keep
+    g.tables.meta["irregular"]["lookahead_row"][5, 0] = g.tables.T
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc == _capi.ERR_INVALID and "lookahead_row" in msg
+    assert irr is None or True
+
+
+def test_create_rejects_a_negative_log_capacity():
+    g = load_trace("ct2_pv_nodeg")
+    p = params_for(g)
+    p.log_data, p.log_capacity = 1, -5
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc == _capi.ERR_INVALID and "log_capacity" in msg

@@ -11,8 +11,10 @@ from fleetrl_amd import _capi
 pytestmark = pytest.mark.gpu
 
 
+# the two *_q7* traces: init_soh at / just above 0.9, so the sticky raised target (quirk Q7) feeds the distributed rule
+# (get_dist_factor uses target_soc, fleet_environment.py:782-799) and the reset laxity fix-up of the episodes after it
 @pytest.mark.parametrize("policy", [_capi.POLICY_UNCONTROLLED, _capi.POLICY_DISTRIBUTED])
-@pytest.mark.parametrize("name", ["ct5_both_rainflow", "lmd5_price_linear"])
+@pytest.mark.parametrize("name", ["ct5_both_rainflow", "lmd5_price_linear", "lmd3_price_linear_q7cross", "ct3_both_nodeg_q7sticky"])
 def test_policy_rollout_matches_stepwise_oracle(name, policy):
     import torch
 
@@ -48,6 +50,9 @@ def test_policy_rollout_matches_stepwise_oracle(name, policy):
     np.testing.assert_array_equal(hip.get("time_idx"), cpu.get("time_idx"))
     np.testing.assert_allclose(hip.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(hip.get("soh"), cpu.get("soh"), rtol=1e-9)
+    np.testing.assert_array_equal(hip.get("target_soc"), cpu.get("target_soc"))
+    if "q7" in name:
+        assert (hip.get("target_soc") == 0.9).any()
     hip.check_errors()
 
 
