@@ -193,6 +193,10 @@ def load_library():
     lib.fleet_check_errors.argtypes = [vp]
     lib.fleet_timer_start.argtypes = [vp]
     lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.fleet_last_step_episodes.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_double)),
+                                             C.POINTER(C.POINTER(C.c_int32))]
+    lib.fleet_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.fleet_host_free.argtypes = [vp]
     lib.fleet_timer_mark.argtypes = [vp]
     lib.fleet_timer_read.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
@@ -201,7 +205,8 @@ def load_library():
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
-                 "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev"):
+                 "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
+                 "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -214,4 +219,5 @@ EXPORTED_SYMBOLS = (
     "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
+    "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes",
 )

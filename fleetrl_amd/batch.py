@@ -33,6 +33,8 @@ class FleetBatch:
         self.E, self.N = int(params.num_envs), int(params.num_cars)
         self.obs_dim = int(self.lib.fleet_obs_dim(C.byref(params)))
         self._term = None
+        self._pinned = []      # (address, numpy view) of the pinned observation buffers handed out by step()
+        self._pin_next = 0
 
     # ------------------------------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -43,6 +45,21 @@ class FleetBatch:
         if getattr(self, "h", None):
             self.lib.fleet_destroy(self.h)
             self.h = None
+        for addr, _view in getattr(self, "_pinned", []):
+            self.lib.fleet_host_free(C.c_void_p(addr))
+        self._pinned = []
+
+    def pinned_array(self, shape, dtype=np.float32) -> np.ndarray:
+        """A NumPy array in pinned (page-locked) host memory (`fleet_host_alloc`): the host entry points move such buffers
+        over PCIe without staging.  Owned by this batch: valid until close()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        out = C.c_void_p()
+        rc = self.lib.fleet_host_alloc(n, C.byref(out))
+        if rc != _capi.OK:
+            raise FleetHipError(rc, "fleet_host_alloc failed")
+        view = np.frombuffer((C.c_char * n).from_address(out.value), dtype=dtype).reshape(shape)
+        self._pinned.append((out.value, view))
+        return view
 
     def __del__(self):
         try:
@@ -120,11 +137,21 @@ class FleetBatch:
             raise ValueError(f"actions must have shape {shape}, got {a.shape}")
         return a, dt
 
-    def step(self, actions):
+    OBS_RING = 4  # pinned observation buffers step() cycles through
+
+    def step(self, actions, fresh_obs: bool = False):
         """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim]); `terminal_obs` is a buffer
-        reused between calls whose rows are valid only where `done` is set."""
+        reused between calls whose rows are valid only where `done` is set.  `obs` is one of OBS_RING pinned buffers used in
+        turn (the transfer lands in it directly): it stays valid for the next OBS_RING - 1 calls -- enough for an SB3 /
+        gymnasium loop, which holds the previous observation while it steps -- pass `fresh_obs=True` for a private copy."""
         a, dt = self._act(actions, (self.E, self.N))
-        obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
+        if fresh_obs:
+            obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
+        else:
+            if len(self._pinned) < self.OBS_RING:
+                self.pinned_array((self.E, self.obs_dim))
+            obs = self._pinned[self._pin_next % self.OBS_RING][1]
+            self._pin_next += 1
         if self._term is None:  # reused across steps: only the rows of envs that just finished are meaningful
             self._term = np.zeros((self.E, self.obs_dim), dtype=np.float32)
         term = self._term
@@ -133,6 +160,16 @@ class FleetBatch:
         self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,
                                               done.ctypes.data, term.ctypes.data))
         return obs, rew, done, term
+
+    def last_step_episodes(self):
+        """(env indices, returns, lengths) of the episodes that ended in the last `step()` -- already on the host, no launch."""
+        n = C.c_int32()
+        idx, ret, ln = C.POINTER(C.c_int32)(), C.POINTER(C.c_double)(), C.POINTER(C.c_int32)()
+        self._check(self.lib.fleet_last_step_episodes(self.h, C.byref(n), C.byref(idx), C.byref(ret), C.byref(ln)))
+        k = int(n.value)
+        if k == 0:
+            return np.zeros(0, np.int32), np.zeros(0), np.zeros(0, np.int32)
+        return (np.ctypeslib.as_array(idx, (k,)).copy(), np.ctypeslib.as_array(ret, (k,)).copy(), np.ctypeslib.as_array(ln, (k,)).copy())
 
     # ---- device-pointer path (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) -------------------
     def reset_dev(self, obs_ptr: int, mask_ptr: int | None = None):

@@ -33,6 +33,16 @@ struct Batch {
   double* st_reward = nullptr;
   uint8_t* st_done = nullptr;
   uint8_t* st_mask = nullptr;
+  // host path: {reward f64[E], finished-episode returns f64[E], count i32 (+pad), idx i32[E], lengths i32[E], done u8[E]} in
+  // ONE device block = one transfer; the
+  // compacted terminal rows; pinned host mirrors (PCIe at full rate, no pageable staging by the runtime)
+  char* st_small = nullptr;
+  size_t small_bytes = 0, small_off_count = 0, small_off_idx = 0, small_off_done = 0, small_off_ret = 0, small_off_len = 0;
+  float* st_term_compact = nullptr;
+  char* pin_small = nullptr;
+  void* pin_actions = nullptr;
+  float* pin_term = nullptr;
+  bool host_step_has_episodes = false;
   double* st_dist = nullptr;
   int32_t* dev_sched = nullptr;
   FleetCold cold_host{};
@@ -413,8 +423,21 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, (char**)&b->st_actions, EN * 8))) return rc;
   if ((rc = dev_alloc(b, &b->st_obs, OD))) return rc;
   if ((rc = dev_alloc(b, &b->st_term, OD))) return rc;
-  if ((rc = dev_alloc(b, &b->st_reward, E))) return rc;
-  if ((rc = dev_alloc(b, &b->st_done, E))) return rc;
+  {
+    b->small_off_ret = (size_t)E * 8;
+    b->small_off_count = b->small_off_ret + (size_t)E * 8;
+    b->small_off_idx = b->small_off_count + 8;
+    b->small_off_len = b->small_off_idx + (size_t)E * 4;
+    b->small_off_done = b->small_off_len + (size_t)E * 4;
+    b->small_bytes = b->small_off_done + (size_t)E;
+    if ((rc = dev_alloc(b, &b->st_small, b->small_bytes))) return rc;
+    b->st_reward = reinterpret_cast<double*>(b->st_small);
+    b->st_done = reinterpret_cast<uint8_t*>(b->st_small + b->small_off_done);
+    if ((rc = dev_alloc(b, &b->st_term_compact, OD))) return rc;
+    HIP_TRY(b, hipHostMalloc((void**)&b->pin_small, b->small_bytes, hipHostMallocDefault));
+    HIP_TRY(b, hipHostMalloc(&b->pin_actions, EN * 8, hipHostMallocDefault));
+    HIP_TRY(b, hipHostMalloc((void**)&b->pin_term, OD * sizeof(float), hipHostMallocDefault));
+  }
   if ((rc = dev_alloc(b, &b->st_mask, E))) return rc;
   if ((rc = dev_alloc(b, &b->st_dist, EN))) return rc;
   if ((rc = dev_alloc(b, (char**)&b->st_field, EN * 8))) return rc;
@@ -467,6 +490,8 @@ int fleet_destroy(fleet_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   for (void* ptr : h->allocs) (void)hipFree(ptr);
+  for (void* ptr : {(void*)h->pin_small, h->pin_actions, (void*)h->pin_term})
+    if (ptr) (void)hipHostFree(ptr);
   if (h->dev_sched) (void)hipFree(h->dev_sched);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
@@ -623,26 +648,76 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
     return FLEET_ERR_INVALID;
   }
   HIP_TRY(h, hipSetDevice(h->device));
-  const size_t EN = (size_t)h->d.E * h->d.N;
-  const size_t OD = (size_t)h->d.E * h->d.obs_dim * sizeof(float);
-  HIP_TRY(h, hipMemcpyAsync(h->st_actions, actions, EN * (act_dtype == FLEET_ACT_F64 ? 8 : 4), hipMemcpyHostToDevice, h->stream));
+  const int E = h->d.E;
+  const size_t EN = (size_t)E * h->d.N;
+  const size_t row = (size_t)h->d.obs_dim * sizeof(float);
+  const size_t OD = (size_t)E * row;
+  const size_t abytes = EN * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
+  // Action buffers from fleet_host_alloc are pinned: the transfer runs straight out of them.  Anything else goes through the
+  // handle's pinned mirror (one small memcpy on the host instead of the runtime's pageable staging).
+  hipPointerAttribute_t attr;
+  auto pinned = [&](const void* p) {
+    return hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+  };
+  const bool act_pinned = pinned(actions);
+  (void)hipGetLastError();  // hipPointerGetAttributes on a pageable pointer leaves an error code behind
+  const void* asrc = actions;
+  if (!act_pinned) {
+    memcpy(h->pin_actions, actions, abytes);
+    asrc = h->pin_actions;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->st_actions, asrc, abytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, fleet_launch_step(h->d, h->st_actions, act_dtype, 1, h->st_obs, h->st_reward, h->st_done,
                                terminal_obs ? h->st_term : nullptr, nullptr, h->stream));
+  if (terminal_obs)
+    HIP_TRY(h, fleet_launch_term_compact(h->d, h->st_done, h->st_term, reinterpret_cast<int32_t*>(h->st_small + h->small_off_idx),
+                                         reinterpret_cast<int32_t*>(h->st_small + h->small_off_count),
+                                         reinterpret_cast<double*>(h->st_small + h->small_off_ret),
+                                         reinterpret_cast<int32_t*>(h->st_small + h->small_off_len), h->st_term_compact, h->stream));
+  h->host_step_has_episodes = terminal_obs != nullptr;
+  HIP_TRY(h, hipMemcpyAsync(h->pin_small, h->st_small, h->small_bytes, hipMemcpyDeviceToHost, h->stream));
+  // the observations go straight to the caller's buffer: at the link rate if it is pinned, through the runtime's chunked
+  // staging otherwise (measured faster than one pinned mirror + a 6 MB memcpy on the host)
   HIP_TRY(h, hipMemcpyAsync(obs, h->st_obs, OD, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(reward, h->st_reward, h->d.E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(done, h->st_done, h->d.E, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  memcpy(reward, h->pin_small, (size_t)E * 8);
+  memcpy(done, h->pin_small + h->small_off_done, (size_t)E);
   if (terminal_obs) {
-    // terminal observations only exist for envs that finished in this step: move them (a full-size transfer
-    // otherwise) only when there is one; rows of envs that did not finish are left untouched
-    bool any = false;
-    for (int e = 0; e < h->d.E && !any; ++e) any = done[e] != 0;
-    if (any) {
-      HIP_TRY(h, hipMemcpyAsync(terminal_obs, h->st_term, OD, hipMemcpyDeviceToHost, h->stream));
+    // terminal observations only exist for the envs that finished in this step: only those rows cross PCIe; rows of envs
+    // that did not finish are left untouched
+    const int n = *reinterpret_cast<const int32_t*>(h->pin_small + h->small_off_count);
+    if (n > 0) {
+      const int32_t* idx = reinterpret_cast<const int32_t*>(h->pin_small + h->small_off_idx);
+      HIP_TRY(h, hipMemcpyAsync(h->pin_term, h->st_term_compact, (size_t)n * row, hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
+      for (int k = 0; k < n; ++k) memcpy(terminal_obs + (size_t)idx[k] * h->d.obs_dim, h->pin_term + (size_t)k * h->d.obs_dim, row);
     }
   }
   return FLEET_OK;
+}
+
+int fleet_last_step_episodes(fleet_handle h, int32_t* n, const int32_t** env_idx, const double** ep_return, const int32_t** ep_len) {
+  if (!h || !n) return FLEET_ERR_INVALID;
+  if (!h->host_step_has_episodes) {
+    h->error = "fleet_last_step_episodes: needs a preceding fleet_step_host with a terminal_obs buffer";
+    return FLEET_ERR_INVALID;
+  }
+  *n = *reinterpret_cast<const int32_t*>(h->pin_small + h->small_off_count);
+  if (env_idx) *env_idx = reinterpret_cast<const int32_t*>(h->pin_small + h->small_off_idx);
+  if (ep_return) *ep_return = reinterpret_cast<const double*>(h->pin_small + h->small_off_ret);
+  if (ep_len) *ep_len = reinterpret_cast<const int32_t*>(h->pin_small + h->small_off_len);
+  return FLEET_OK;
+}
+
+int fleet_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return FLEET_ERR_INVALID;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? FLEET_OK : FLEET_ERR_HIP;
+}
+
+int fleet_host_free(void* p) {
+  if (!p) return FLEET_OK;
+  return hipHostFree(p) == hipSuccess ? FLEET_OK : FLEET_ERR_HIP;
 }
 
 static size_t field_bytes(const FleetDev& d, int field) {

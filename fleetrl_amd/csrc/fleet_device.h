@@ -197,6 +197,9 @@ struct FleetDev {
 hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs, hipStream_t s);
 hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                              uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s);
+// compact the terminal observations of the envs with done[e] != 0 (env order): idx[k], *count, compact[k, obs_dim]
+hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,
+                                     double* ep_ret, int32_t* ep_len, float* compact, hipStream_t s);
 hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t s);
 // unpack state planes for fleet_get: field ids of include/fleet_hip.h -> contiguous device buffer `out`
 hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s);

@@ -1050,6 +1050,52 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
   }
 }
 
+// Host path: the terminal observations of the envs that finished in this step, compacted (fleet_step_host moves only these
+// rows over PCIe instead of the whole [E, obs_dim] buffer).  One workgroup: a serial-over-chunks scan of the done flags in
+// env order (deterministic), then the rows are copied by the whole launch.
+__global__ __launch_bounds__(1024) void fleet_term_scan_kernel(const uint8_t* __restrict__ done, int E, int32_t* __restrict__ idx,
+                                                               int32_t* __restrict__ count, const EnvRec* __restrict__ env,
+                                                               double* __restrict__ ep_ret, int32_t* __restrict__ ep_len) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int e0 = 0; e0 < E; e0 += 1024) {
+    const int e = e0 + (int)threadIdx.x;
+    const bool f = (e < E) && done[e] != 0;
+    const unsigned long long m = __ballot(f);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (f) {  // the finished episode's return / length travel with the index (what SB3's Monitor would report)
+      idx[off + before] = e;
+      ep_ret[off + before] = env[e].last_ep_return;
+      ep_len[off + before] = env[e].last_ep_len;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = s_base;
+}
+
+__global__ void fleet_term_gather_kernel(const float* __restrict__ term, int obs_dim, const int32_t* __restrict__ idx,
+                                         const int32_t* __restrict__ count, float* __restrict__ compact) {
+  const int n = *count;
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    const float* src = term + (size_t)idx[k] * obs_dim;
+    float* dst = compact + (size_t)k * obs_dim;
+    for (int j = threadIdx.x; j < obs_dim; j += blockDim.x) dst[j] = src[j];
+  }
+}
+
 int group_size(int N) {
   int G = 1;
   while (G < N && G < 64) G <<= 1;
@@ -1130,6 +1176,13 @@ hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dty
 #define CALL(Gv) launch_step_g<Gv>(d, actions, act_dtype, K, obs, reward, done, terminal_obs, done_count, s)
   FLEET_DISPATCH_G(d.N, CALL)
 #undef CALL
+}
+
+hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,
+                                     double* ep_ret, int32_t* ep_len, float* compact, hipStream_t s) {
+  hipLaunchKernelGGL(fleet_term_scan_kernel, dim3(1), dim3(1024), 0, s, done, d.E, idx, count, d.env, ep_ret, ep_len);
+  hipLaunchKernelGGL(fleet_term_gather_kernel, dim3(256), dim3(256), 0, s, term, d.obs_dim, idx, count, compact);
+  return hipGetLastError();
 }
 
 hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t s) {

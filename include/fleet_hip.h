@@ -22,6 +22,7 @@
 #ifndef FLEET_HIP_H
 #define FLEET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -240,6 +241,17 @@ int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);
 /* terminal_obs (or NULL): rows of envs that finished in this step are written; all other rows are left untouched */
 int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
                     uint8_t* done, float* terminal_obs);
+
+/* The episodes that ended in the last fleet_step_host call (the one with a terminal_obs buffer): their env indices in
+ * ascending order, returns (episode.cumulative_reward) and lengths -- what SB3's Monitor wrapper would put into
+ * info["episode"].  The pointers refer to the handle's own host buffer and stay valid until the next step. */
+int fleet_last_step_episodes(fleet_handle h, int32_t* n, const int32_t** env_idx, const double** ep_return, const int32_t** ep_len);
+
+/* Pinned (page-locked) host memory for the *_host entry points: observations / actions in such buffers cross PCIe straight
+ * out of / into them at the full link rate; any other host pointer is staged through the handle's own pinned mirrors (one
+ * extra memcpy).  Independent of any handle; free with fleet_host_free. */
+int fleet_host_alloc(size_t bytes, void** out);
+int fleet_host_free(void* p);
 
 /* ---- state access ------------------------------------------------------------------------------------- */
 int fleet_get(fleet_handle h, int field, void* out_host);
