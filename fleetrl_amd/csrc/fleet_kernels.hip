@@ -725,6 +725,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     }
 
     double cash = 0.0, rew = 0.0, asum = 0.0, penrec = 0.0, miss_sum = 0.0;
+    // what the daily SEI pass needs of the lane's EV, carried in registers when a lane owns one EV (no reload round trip for
+    // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
+    double sei_sample = 0.0, sei_soh = 0.0;
+    int sei_tail = 0, sei_head = 0;
+    RfTop sei_top = {0.0, 0.0};
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
@@ -849,6 +854,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         }
       }
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
+      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
+        sei_sample = soc_deg;
+        sei_soh = soh0;
+        sei_tail = tail;
+        sei_head = head;
+        sei_top = top;
+      }
       if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
         double* lev = d.log_ev + lrow * 4 * N + c;
         lev[0] = a;
@@ -924,8 +936,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     FLEET_STAMP(7);
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
-    // (transcendentals, accumulators) never coexist with the hot path's registers; the few words it needs are re-read
-    // from the records this lane has just stored.  One step in 96, and wave-uniform for G == 64.
+    // (transcendentals, accumulators) never coexist with the hot path's registers.  One step in 96, and wave-uniform for
+    // G == 64.
 #if defined(FLEET_ABL_NO_EVAL) || defined(FLEET_ABL_NO_RARE)
     if (false) {
 #else
@@ -933,11 +945,21 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 #endif
       for (int c = g; c < N; c += G) {
         const size_t i = (size_t)e * N + c;
-        const Hot hb = d.hot[i];
-        const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
-        const RfTop top = d.rf_top[i];
-        const double deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
-        const double soh_new = d.soh[i] - deg;
+        double deg, soh_new;
+#ifdef FLEET_ABL_SEI_RELOAD  // diagnostic: the round-1 form (always re-read)
+        if (false) {
+#else
+        if (!WIDE) {
+#endif
+          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_head, sei_top, err, dt_step);
+          soh_new = sei_soh - deg;
+        } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
+          const Hot hb = d.hot[i];
+          const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
+          const RfTop top = d.rf_top[i];
+          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
+          soh_new = d.soh[i] - deg;
+        }
         d.soh[i] = soh_new;
         if (logs) {
           double* lev = d.log_ev + lrow * 4 * N + c;

@@ -440,7 +440,14 @@ def build_tables_from_config(cfg: dict, schedule: Schedule | None = None) -> Fle
     rc = resolve_config(cfg)
     path = cfg["data_path"]
     if schedule is None:
-        schedule = load_schedule_csv(os.path.join(path, cfg["schedule_name"]))
+        name = cfg["schedule_name"]
+        if cfg.get("gen_schedule"):
+            # `FleetEnv.auto_gen` (fleet_environment.py:180-182, 969-992): generate `gen_n_evs` vehicles, save them as
+            # <data_path>/<gen_name>.csv and use that file -- here with the vectorised generator, in milliseconds
+            from .schedule_gen import generate_from_config
+
+            name = generate_from_config(cfg)
+        schedule = load_schedule_csv(os.path.join(path, name))
     spot = _read_hourly(os.path.join(path, cfg["price_name"]), _SPOT_COLUMN, ";", ",")
     tariff = _read_hourly(os.path.join(path, cfg["tariff_name"]), "tariff", ";", ",")
     load = pv = None
