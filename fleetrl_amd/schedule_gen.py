@@ -35,7 +35,7 @@ import numpy as np
 
 from .prestage import Schedule
 
-__all__ = ["ScheduleStats", "schedule_stats_for", "generate_schedule", "generate_schedule_frame", "write_schedule_csv",
+__all__ = ["ScheduleStats", "schedule_stats_for", "generate_schedule", "generate_schedule_arrays", "generate_schedule_frame", "write_schedule_csv",
            "generate_from_config"]
 
 
@@ -169,36 +169,53 @@ def _vehicle(stats: ScheduleStats, rng: np.random.Generator, dow: np.ndarray, sp
     return driving, distance, consumption
 
 
-def generate_schedule_frame(use_case: str, n_evs: int, start_date, end_date, *, seed: int = 0, env_config: dict | None = None,
-                            identical_vehicles: bool = False, minutes: int = 15):
-    """-> pandas DataFrame in the reference's schema for vehicles 0..n_evs-1, rows `pd.date_range(start, end, freq=15 min)`
-    (end inclusive; a delivery / utility / custom schedule that would start on a Sunday starts on the Monday, :74-83)."""
-    import pandas as pd
-
+def generate_schedule_arrays(use_case: str, n_evs: int, start_date, end_date, *, seed: int = 0, env_config: dict | None = None,
+                             identical_vehicles: bool = False, minutes: int = 15):
+    """-> (dates datetime64[s] [T], driving bool [n_evs, T], distance_km [n_evs, T], consumption_kwh [n_evs, T], charger kW) for
+    the rows `pd.date_range(start, end, freq=15 min)` (end inclusive; a delivery / utility / custom schedule that would start
+    on a Sunday starts on the Monday, :74-83)."""
     if minutes != 15:
         raise ValueError("the reference's generator is written for 15-minute rows (trip rows = hours * 4)")
     stats = schedule_stats_for(use_case, env_config)
-    dates = pd.date_range(start=start_date, end=end_date, freq="15min")
+    t0 = np.datetime64(str(start_date).replace(" ", "T"), "s")
+    t1 = np.datetime64(str(end_date).replace(" ", "T"), "s")
+    step = np.timedelta64(900, "s")
+    dates = t0 + np.arange(int((t1 - t0) // step) + 1) * step
+    weekday = lambda d: int((d.astype("datetime64[D]").astype(np.int64) + 3) % 7)  # noqa: E731  Monday = 0
     if stats.kind != "caretaker":
-        while len(dates) and dates[0].weekday() == 6:
+        while dates.size and weekday(dates[0]) == 6:
             dates = dates[1:]
-    if len(dates) == 0:
+    if dates.size == 0:
         raise ValueError("empty date range")
     spd = 96
-    first_slot = dates[0].hour * 4 + dates[0].minute // 15
-    day0 = dates[0].normalize()
-    days = int(((dates[-1].normalize() - day0).days) + 1)
-    dow = (day0.weekday() + np.arange(days)) % 7
-    parts = []
+    day0 = dates[0].astype("datetime64[D]")
+    first_slot = int((dates[0] - day0.astype("datetime64[s]")) // step)
+    days = int((dates[-1].astype("datetime64[D]") - day0).astype(np.int64)) + 1
+    dow = (weekday(dates[0]) + np.arange(days)) % 7
+    T = dates.size
+    driving = np.zeros((n_evs, T), dtype=bool)
+    distance = np.zeros((n_evs, T))
+    consumption = np.zeros((n_evs, T))
     for ev in range(n_evs):
         rng = np.random.Generator(np.random.Philox(key=[int(seed), 0 if identical_vehicles else ev + 1]))
-        driving, distance, consumption = _vehicle(stats, rng, dow, spd)
-        sl = slice(first_slot, first_slot + len(dates))
-        drv = driving[sl]
+        drv, dist, cons = _vehicle(stats, rng, dow, spd)
+        sl = slice(first_slot, first_slot + T)
+        driving[ev], distance[ev], consumption[ev] = drv[sl], dist[sl], cons[sl]
+    return dates, driving, distance, consumption, float(stats.power)
+
+
+def generate_schedule_frame(use_case: str, n_evs: int, start_date, end_date, **kw):
+    """-> pandas DataFrame in the reference's schema for vehicles 0..n_evs-1 (see generate_schedule_arrays)."""
+    import pandas as pd
+
+    dates, driving, distance, consumption, power = generate_schedule_arrays(use_case, n_evs, start_date, end_date, **kw)
+    parts = []
+    for ev in range(n_evs):
+        drv = driving[ev]
         parts.append(pd.DataFrame({
-            "date": dates, "Distance_km": distance[sl], "Consumption_kWh": consumption[sl],
+            "date": pd.DatetimeIndex(dates), "Distance_km": distance[ev], "Consumption_kWh": consumption[ev],
             "Location": np.where(drv, "driving", "home"), "ChargingStation": np.where(drv, "none", "home"),
-            "ID": ev, "PowerRating_kW": np.where(drv, 0.0, float(stats.power))}))
+            "ID": ev, "PowerRating_kW": np.where(drv, 0.0, power)}))
     return pd.concat(parts)  # like `pd.concat(gen_sched)` (:986): every vehicle keeps its own 0..T-1 index
 
 
@@ -209,12 +226,13 @@ def write_schedule_csv(frame, path: str) -> str:
 
 
 def generate_schedule(use_case: str, n_evs: int, start_date, end_date, **kw) -> Schedule:
-    """The same as a `prestage.Schedule` (what the pre-stager consumes), without the CSV detour."""
-    f = generate_schedule_frame(use_case, n_evs, start_date, end_date, **kw)
-    station = f["ChargingStation"].values.astype(str)
-    return Schedule(date=f["date"].values.astype("datetime64[s]"), ev_id=f["ID"].values.astype(np.int64),
-                    consumption=f["Consumption_kWh"].values.astype(np.float64), power_rating=f["PowerRating_kW"].values.astype(np.float64),
-                    station_none=(station == "none"), station_code=(station == "none").astype(np.int64))
+    """The same as a `prestage.Schedule` (what the pre-stager consumes), without the DataFrame / CSV detour."""
+    dates, driving, _distance, consumption, power = generate_schedule_arrays(use_case, n_evs, start_date, end_date, **kw)
+    T = dates.size
+    drv = driving.reshape(-1)
+    return Schedule(date=np.tile(dates, n_evs), ev_id=np.repeat(np.arange(n_evs, dtype=np.int64), T),
+                    consumption=consumption.reshape(-1), power_rating=np.where(drv, 0.0, power), station_none=drv.copy(),
+                    station_code=drv.astype(np.int64))
 
 
 def generate_from_config(cfg: dict) -> str:

@@ -2,13 +2,10 @@
 
 The reference ships only single-EV schedules (the multi-EV blobs `inputs/2_*.csv` are missing)
 and its own generator is an O(T^2) pandas loop that takes hours (`ScheduleGenerator`,
-/root/reference/fleetrl/utils/schedule/schedule_generator.py:64-691).  This module draws N-EV schedules directly
-in array form, O(T*N), with the same per-use-case statistics (`ScheduleConfig`, schedule_config.py:26-132:
-departure/return time means and deviations, weekday/weekend split, caretaker lunch pause, distance and
-consumption distributions with their clips) and an independent random stream per vehicle (the reference seeds
-every vehicle identically, schedule_generator.py:31-32, which makes all vehicles the same -- deliberately not
-replicated).  Prices, building load and PV are hourly synthetic series with the magnitude and daily/seasonal shape
-of the shipped German 2020 data.  Everything is seeded, nothing is read from disk.
+/root/reference/fleetrl/utils/schedule/schedule_generator.py:64-691).  N-EV schedules come from the package's vectorised
+generator (fleetrl_amd/schedule_gen.py: the reference's sampling rules and `ScheduleConfig` statistics, O(T*N), an
+independent random stream per vehicle).  Prices, building load and PV are hourly synthetic series with the magnitude and
+daily/seasonal shape of the shipped German data.  Everything is seeded, nothing is read from disk.
 """
 from __future__ import annotations
 
@@ -16,91 +13,17 @@ import numpy as np
 
 from .prestage import FleetTables, Schedule, build_tables
 
-__all__ = ["synth_schedule", "synth_hourly", "synth_tables", "USE_CASES"]
-
-# (dep mean/std wd, ret mean/std wd, dep mean/std we, ret mean/std we, min_dep, max_dep, min_ret, max_ret,
-#  dist mean/std wd, dist mean/std we, min/max dist, cons mean/std/min/max kWh/km, trip clip kWh, charger kW)
-USE_CASES = {
-    "lmd": dict(dep_wd=(7, 1), ret_wd=(19, 1), dep_we=(9, 1.5), ret_we=(17, 1.5), dep_lim=(3, 11), ret_lim=(12, 23),
-                dist_wd=(150, 25), dist_we=(75, 25), dist_lim=(20, 280), cons=(0.213, 0.167463672468669, 0.0994, 0.453),
-                clip=50.0, power=11.0, sunday=0.0, saturday=1.0),
-    "ut": dict(dep_wd=(7, 1), ret_wd=(19, 1), dep_we=(9, 2), ret_we=(16, 2), dep_lim=(3, 11), ret_lim=(12, 23),
-               dist_wd=(120, 30), dist_we=(80, 25), dist_lim=(20, 220), cons=(0.224, 0.167463672468669, 0.0994, 0.453),
-               clip=41.0, power=22.0, sunday=0.05, saturday=1.0),
-    "ct": dict(dep_wd=(6, 1), ret_wd=(19, 1), dep_we=(9, 1.5), ret_we=(15, 1.5), dep_lim=(3, 10), ret_lim=(15, 23),
-               pause_beg=(12, 0.25), pause_end_wd=(13.5, 0.25), pause_end_we=(13, 0.25),
-               dist_wd=(30, 10), dist_we=(15, 15), dist_lim=(5, 50), cons=(0.17, 0.167463672468669, 0.0994, 0.453),
-               clip=13.5, clip_afternoon=10.0, power=4.7, sunday=1.0, saturday=1.0),
-}
-
-
-def _clip_normal(rng, mean_std, lo, hi, size):
-    return np.clip(rng.normal(mean_std[0], mean_std[1], size=size), lo, hi)
-
+__all__ = ["synth_schedule", "synth_hourly", "synth_tables"]
 
 def synth_schedule(use_case: str, n_evs: int, seed: int = 1234, year: int = 2020, days: int = 365,
                    minutes: int = 15) -> Schedule:
-    """N-EV schedule on a regular grid starting `year`-01-01 00:00 (same span as the shipped files: 365 days)."""
-    uc = USE_CASES[use_case]
-    sph = 60 // minutes
-    spd = 24 * sph
-    T = days * spd
-    start = np.datetime64(f"{year}-01-01T00:00:00", "s")
-    dates = start + np.arange(T) * np.timedelta64(minutes * 60, "s")
-    weekday0 = int((start.astype("datetime64[D]").astype(np.int64) + 3) % 7)
-    dow = (weekday0 + np.arange(days)) % 7  # Monday = 0
+    """N-EV schedule on a regular grid starting `year`-01-01 00:00 (same span as the shipped files: 365 days), drawn by the
+    package's schedule generator (fleetrl_amd/schedule_gen.py: the reference's sampling rules, one Philox stream per vehicle)."""
+    from .schedule_gen import generate_schedule
 
-    driving = np.zeros((n_evs, T), dtype=bool)
-    cons = np.zeros((n_evs, T))
-    for ev in range(n_evs):
-        rng = np.random.default_rng([seed, ev])
-        we = dow >= 5
-        active = np.where(dow == 6, rng.random(days) < uc["sunday"], np.where(dow == 5, rng.random(days) < uc["saturday"], True))
-        dep = np.where(we, _clip_normal(rng, uc["dep_we"], *uc["dep_lim"], days), _clip_normal(rng, uc["dep_wd"], *uc["dep_lim"], days))
-        ret = np.where(we, _clip_normal(rng, uc["ret_we"], *uc["ret_lim"], days), _clip_normal(rng, uc["ret_wd"], *uc["ret_lim"], days))
-        dist = np.where(we, _clip_normal(rng, uc["dist_we"], *uc["dist_lim"], days), _clip_normal(rng, uc["dist_wd"], *uc["dist_lim"], days))
-        c_km = np.clip(rng.normal(uc["cons"][0], uc["cons"][1], size=days), uc["cons"][2], uc["cons"][3])
-        legs = []  # (start slot, end slot (exclusive), kWh) per day
-        if use_case == "ct":
-            pb = _clip_normal(rng, uc["pause_beg"], 11.0, 12.75, days)
-            pe = np.where(we, _clip_normal(rng, uc["pause_end_we"], 12.5, 14.0, days), _clip_normal(rng, uc["pause_end_wd"], 13.0, 14.5, days))
-            pe = np.maximum(pe, pb + 0.5)
-            ret = np.maximum(ret, pe + 1.0)
-            share = rng.uniform(0.4, 0.6, size=days)
-            legs.append((dep, pb, np.minimum(dist * share * c_km, uc["clip"])))
-            legs.append((pe, ret, np.minimum(dist * (1 - share) * c_km, uc["clip_afternoon"])))
-        else:
-            ret = np.maximum(ret, dep + 1.0)
-            legs.append((dep, ret, np.minimum(dist * c_km, uc["clip"])))
-        for a, b, kwh in legs:
-            sa = np.floor(a * sph).astype(np.int64)
-            sb = np.maximum(np.ceil(b * sph).astype(np.int64), sa + 1)
-            sb = np.minimum(sb, spd - 1)  # always home again before midnight
-            days_on = np.nonzero(active)[0]
-            r0 = days_on * spd + sa[days_on]
-            r1 = days_on * spd + sb[days_on]
-            # paint the [r0, r1) runs with a difference array (runs of one leg never overlap)
-            per_slot = kwh[days_on] / (r1 - r0)
-            diff = np.zeros(T + 1)
-            np.add.at(diff, r0, per_slot)
-            np.add.at(diff, r1, -per_slot)
-            flag = np.zeros(T + 1, dtype=np.int64)
-            np.add.at(flag, r0, 1)
-            np.add.at(flag, r1, -1)
-            on = np.cumsum(flag[:T]) > 0
-            # exact per-slot value (a running float sum would accumulate rounding): index of the run each slot belongs to
-            run_id = np.cumsum(np.isin(np.arange(T), r0)) - 1
-            cons[ev, on] += per_slot[run_id[on]]
-            driving[ev, on] = True
-    power = np.where(driving, 0.0, uc["power"])
-    return Schedule(
-        date=np.tile(dates, n_evs),
-        ev_id=np.repeat(np.arange(n_evs, dtype=np.int64), T),
-        consumption=cons.reshape(-1),
-        power_rating=power.reshape(-1),
-        station_none=driving.reshape(-1),
-        station_code=driving.reshape(-1).astype(np.int64),
-    )
+    start = np.datetime64(f"{year}-01-01T00:00:00", "s")
+    end = start + np.timedelta64((days * 24 * 60 // minutes - 1) * minutes * 60, "s")
+    return generate_schedule(use_case, n_evs, str(start), str(end), seed=seed, minutes=minutes)
 
 
 # level / spread of the two price years the reference ships (inputs/spot_2020_new.csv: mean 30.4, std 17.5 EUR/MWh;

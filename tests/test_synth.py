@@ -13,7 +13,10 @@ def test_synth_tables_are_consistent():
     assert np.all(tb.time_left[away] == 0) and np.all(tb.soc_on_return[away] == 0)
     assert np.all(np.mod(tb.time_left, 0.25) == 0)
     home = tb.there == 1
-    assert tb.soc_on_return[home].min() > 0 and tb.soc_on_return.max() <= 0.85
+    # the caretaker's energy clips (13.5 / 10 kWh per trip on a 16.7 kWh battery, schedule_config.py:94-95) allow a trip to use
+    # more than the lunch target holds -- and a night emergency can run into the morning trip --, so a few returns are below
+    # zero, as with the reference's own generator; the step does not clip either (quirk Q9)
+    assert tb.soc_on_return[home].min() > -0.5 and (tb.soc_on_return[home] > 0).mean() > 0.99 and tb.soc_on_return.max() <= 0.85
     assert not np.isnan(tb.delu).any() and not np.isnan(tb.prc).any()
     # different vehicles get different schedules (the reference generator seeds them identically)
     assert not np.array_equal(tb.there[:, 0], tb.there[:, 1])
