@@ -41,11 +41,20 @@ __device__ unsigned long long fleet_stamp_buf[4096 * 16];
     const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
     if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 16 + (k)] = _t;                       \
   } while (0)
+// wall-clock stamps (s_memrealtime: 100 MHz, one counter for the whole chip) at a wave's entry (slot 9) and exit (slot 10):
+// the launch's timeline across dies, which the per-die shader-clock stamps cannot give
+#define FLEET_STAMP_RT(k)                                                                                \
+  do {                                                                                                   \
+    const unsigned long long _t = __builtin_amdgcn_s_memrealtime();                                      \
+    const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
+    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 16 + (k)] = _t;                       \
+  } while (0)
 extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet_stamp_buf), sizeof(fleet_stamp_buf));
 }
 #else
 #define FLEET_STAMP(k) do {} while (0)
+#define FLEET_STAMP_RT(k) do {} while (0)
 #endif
 
 namespace {
@@ -371,6 +380,10 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
   const int nc = acc.nc;
   const double mean_sum0 = acc.mean_sum, csum0 = acc.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
   const double st = d.stress_temp;
+#ifdef FLEET_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FLEET_STAMP(11);  // records arrived
 
   int nv = 0;
   double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
@@ -415,6 +428,7 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     emit(b, v, 0.5);
   }
 
+  FLEET_STAMP(12);  // stack walked, cycle stresses evaluated
   double degradation = 0.0;
   double sei_l = sei_l0;
   const int len = nc + nv;
@@ -436,6 +450,7 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     acc.csum = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
     *reinterpret_cast<RfAcc*>(row) = acc;
   }
+  FLEET_STAMP(13);  // SEI model evaluated
   const double s = sei_soh0 - degradation;
   sr.sei_soh = s;
   d.sei[i] = sr;
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 #ifdef FLEET_ABL_EMPTY
   if (d.E > 0) return;
 #endif
+  FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
   const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
@@ -680,6 +696,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
+    // the few wavefronts with extra work after the step (daily evaluation, episode end + reset) finish last and set the
+    // launch's duration: they get issue priority over their SIMD's other wavefronts for the step itself (-3 % per launch)
+    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
     const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
 #ifdef FLEET_ABL_TAB_LOCAL  // diagnostic: same loads, table rows of 64 time steps only (cache resident)
     const TabX* __restrict__ tab_t1 = d.tab + (size_t)(t1 & 63) * N;
@@ -1022,6 +1041,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   }
   if (err && env_ok) atomicOr(&d.env[e].err, err);
   FLEET_STAMP(8);
+  FLEET_STAMP_RT(10);
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)

@@ -8,7 +8,7 @@ import glob, sys, pandas as pd
 out = sys.argv[1]
 for p in ("a", "b"):
     c = pd.read_csv(glob.glob(f"{out}/{p}/*/*counter_collection.csv")[0])
-    c = c[c.Kernel_Name.str.contains("fleet_step_kernel") & ~c.Kernel_Name.str.contains("true>")]
+    c = c[c.Kernel_Name.str.contains(r"fleet_step_kernel<\d+, \d+, false,", regex=True)]
     med = c.groupby("Counter_Name").Counter_Value.median()
     w = med["SQ_WAVES"]
     print((med / w).round(1).to_string())

@@ -30,7 +30,7 @@ for name in ("fetch", "write", "l2"):
     if not f:
         continue
     c = pd.read_csv(f[0])
-    c = c[c.Kernel_Name.str.contains("fleet_step_kernel") & c.Kernel_Name.str.contains("false, *(false|true)>", regex=True)]
+    c = c[c.Kernel_Name.str.contains(r"fleet_step_kernel<\d+, \d+, false,", regex=True)]  # the single-step instances
     # per STEP: with several fleet types (c5) a step is one launch per type, all the same kernel instance
     for cn, g in c.groupby("Counter_Name"):
         res[cn] = float(g.Counter_Value.mean()) * n_groups
