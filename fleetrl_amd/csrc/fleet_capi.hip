@@ -132,7 +132,6 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (t->dt_row && !p->real_time) return "an irregular time grid needs real_time = 1";
   if (t->lookahead_row && (t->lookahead_cols < p->price_lookahead || t->lookahead_cols < p->bl_pv_lookahead))
     return "lookahead_cols smaller than a look-ahead";
-  if (p->real_time && p->log_data) return "log_data is not available with real_time";
   if (p->log_capacity < 0) return "negative log_capacity";
   if (t->pick_rows && t->n_pick_rows < 1) return "empty pick_rows";
   if (p->start_lo < 0 || p->start_hi < p->start_lo || p->start_hi > (t->pick_rows ? t->n_pick_rows : p->table_rows) - 1)

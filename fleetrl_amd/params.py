@@ -54,9 +54,6 @@ def validate_supported(rc: ResolvedConfig) -> None:
     if rc.normalize_in_env and rc.include_pv and not rc.include_building:
         raise ValueError("normalize_in_env with include_pv and without include_building crashes in the reference "
                          "(oracle_normalization.py:121); unsupported")
-    if rc.real_time and bool(rc.raw.get("log_data", False)):
-        raise ValueError("log_data with real_time=True is not supported: the reference logs every skipped row "
-                         "(fleet_environment.py:677-690), the device keeps only the last one")
     if rc.deg_mode == DEG_RAINFLOW and rc.init_soh != 1.0:
         raise ValueError("rainflow/SEI degradation with init_soh != 1.0 is ill-defined in the reference "
                          "(rainflow_sei_degradation.py:184); unsupported")

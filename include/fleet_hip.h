@@ -268,7 +268,8 @@ int fleet_get_dist_factor(fleet_handle h, double* out_host);
  *                          price_multiplier and the absolute values are the caller's, :659-661)
  *   ev  [slot,E,4,N]  f64  action, (dis)charging energy per EV [kWh] (ev_charger.py:114,174), degradation, SoH
  *   obs [slot,E,obs_dim] f32  the observation logged with the row
- * The step that ends an episode is not logged (:679); with auto-reset the next row is the reset row of the next episode. */
+ * The step that ends an episode is not logged (:679); with auto-reset the next row is the reset row of the next episode.
+ * With real_time = 1 every table row the skipping loop passes gets its row, like in the reference (:677-690). */
 int fleet_log_capacity(fleet_handle h);  /* rows per env; 0 when the log is off */
 /* copy the ring to HOST buffers (any of them may be NULL); pos [E] = rows written so far per env; synchronous */
 int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs);

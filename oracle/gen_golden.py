@@ -286,6 +286,9 @@ RT_CONFIGS = {
     # the reference's own irregular example: inputs/test_lmd.csv has rows at 00:00, 00:07, 00:15, then every 15 min (per-row dt,
     # fleet_environment.py:994-1022).  Only the load+pv observer runs on it (the others look the window end up by exact date).
     # n_evs = 0: the shipped single-EV file; the first episode of env 0 starts on row 0 and walks the irregular rows.
+    # the reference's DataLogger in real_time mode: a row for EVERY table row of the skipping loop (fleet_environment.py:677-690)
+    "ct3_both_rainflow_log": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                   calculate_degradation=True, deg_emp=False, episode_length=24, real_time=True, log_data=True), 3, 2, 2),
     "lmd1_both_irregular": (dict(use_case="lmd", schedule_name="test_lmd.csv", building_name="load_lmd.csv", include_building=True,
                                  include_pv=True, calculate_degradation=True, deg_emp=True, episode_length=24, real_time=True), 0, 2, 2),
 }
@@ -371,6 +374,30 @@ def run_config_rt(name: str):
                 rec["rf_len"][e, ep] = sd.rainflow_length
                 rec["fd_cyc"][e, ep] = sd.fd_cyc
                 rec["sei_l"][e, ep] = sd.l
+        if ov.get("log_data"):
+            lg = env.data_logger.log.reset_index(drop=True)
+            rows = len(lg)
+            if "log_reward" not in rec:
+                rec.update(log_rows=np.zeros(E, np.int32), log_reward=np.zeros((E, cap)), log_cashflow=np.zeros((E, cap)),
+                           log_penalty=np.zeros((E, cap)), log_grid=np.zeros((E, cap)), log_socv=np.zeros((E, cap)),
+                           log_episode=np.zeros((E, cap), np.int32), log_time=np.zeros((E, cap), np.int64), log_deg=np.zeros((E, cap, N)),
+                           log_charge=np.zeros((E, cap, N)), log_soh=np.zeros((E, cap, N)),
+                           log_obs=np.zeros((E, cap, rec["obs"].shape[2]), np.float32), log_action=np.zeros((E, cap, N)))
+            assert rows <= cap
+            rec["log_rows"][e] = rows
+            rec["log_reward"][e, :rows] = lg["Reward"].astype(float).values
+            rec["log_cashflow"][e, :rows] = lg["Cashflow"].astype(float).values
+            rec["log_penalty"][e, :rows] = lg["Penalties"].astype(float).values
+            rec["log_grid"][e, :rows] = lg["Grid overloading"].astype(float).values
+            rec["log_socv"][e, :rows] = lg["SOC violation"].astype(float).values
+            rec["log_episode"][e, :rows] = lg["Episode"].astype(int).values
+            rec["log_time"][e, :rows] = lg["Time"].values.astype("datetime64[s]").astype(np.int64)
+            for q in range(rows):
+                rec["log_deg"][e, q] = np.broadcast_to(np.asarray(lg["Degradation"].iloc[q], dtype=np.float64), (N,))
+                rec["log_charge"][e, q] = np.asarray(lg["Charging energy"].iloc[q], dtype=np.float64)
+                rec["log_soh"][e, q] = np.asarray(lg["SOH"].iloc[q], dtype=np.float64)
+                rec["log_obs"][e, q] = np.asarray(lg["Observation"].iloc[q], dtype=np.float32)
+                rec["log_action"][e, q] = np.asarray(lg["Action"].iloc[q], dtype=np.float64)
         print(f"  rt {name}: env {e + 1}/{E}: {rec['n_steps'][e].tolist()} agent steps for {ep_rows} rows per episode "
               f"({time.time() - t0:.0f}s)", flush=True)
     N, T = scalars["num_cars"], scalars["table_rows_full"]
@@ -397,7 +424,7 @@ def run_config_rt(name: str):
     out = {f"tab_{k}": v for k, v in tables.items()}
     out.update({f"sc_{k}": np.asarray(v) for k, v in scalars.items()})
     out["cfg_json"] = np.asarray(json.dumps(full_cfg))
-    out.update({k: (v[:, :used] if v.shape[1:2] == (cap,) else v) for k, v in rec.items()})
+    out.update({k: (v[:, :used] if (v.ndim > 1 and v.shape[1] == cap and not k.startswith("log_")) else v) for k, v in rec.items()})
     out["starts"] = starts - w0
     out["time_idx"] = out["time_idx"] - w0
     path = os.path.join(GOLDEN, f"rttrace_{name}.npz")

@@ -76,7 +76,7 @@ def test_obs_dim_formulas_of_the_survey():
 
 def test_unsupported_flag_combinations_are_rejected():
     for upd in (dict(include_price=False), dict(normalize_in_env=True, include_pv=True, include_building=False),
-                dict(real_time=True, log_data=True), dict(init_soh=0.95)):
+                dict(init_soh=0.95)):
         cfg = _cfg()
         cfg.update(upd)
         with pytest.raises(ValueError):

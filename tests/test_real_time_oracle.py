@@ -19,7 +19,7 @@ def test_oracle_real_time_matches_reference(name):
     assert worst["soc"] == 0.0 or worst["soc"] < 1e-12
 
 
-def test_real_time_rejects_irregular_grid_and_data_log():
+def test_real_time_rejects_irregular_grid_without_its_tables():
     import numpy as np
 
     from fleetrl_amd.params import make_params
@@ -35,9 +35,9 @@ def test_real_time_rejects_irregular_grid_and_data_log():
     rc_off = dataclasses.replace(g.rc, real_time=False)
     with pytest.raises(ValueError, match="min apart"):
         make_params(rc_off, bad, 2, extrema=g.extrema, start_range=(0, 0))
+    # log_data with real_time is supported (every row of the skipping loop is logged, tests/test_real_time_gpu.py)
     rc = dataclasses.replace(g.rc, raw={**g.rc.raw, "log_data": True})
-    with pytest.raises(ValueError, match="log_data"):
-        make_params(rc, tb, 2, extrema=g.extrema, start_range=(0, 0))
+    assert make_params(rc, tb, 2, extrema=g.extrema, start_range=(0, 0)).log_data == 1
 
 
 def _irregular_random_params(num_envs):
