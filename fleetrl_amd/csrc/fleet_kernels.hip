@@ -330,11 +330,17 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
     return;
   }
   double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
+#ifndef FLEET_ABL_NO_STK_STORE
   stk[tail] = p;
+#endif
   tail += 1;
   int size = tail - head;  // >= 2: the episode's first sample is always on the stack
   if (size >= 3 && !(fabs(p - b) < fabs(b - a))) {
+#ifdef FLEET_ABL_NO_ACC_RMW  // diagnostic: no accumulator line traffic (wrong results)
+    RfAcc acc = {0.0, 0.0, 0, 1000, 0.0};
+#else
     RfAcc acc = *reinterpret_cast<RfAcc*>(row);
+#endif
     const int L = acc.rf_len;
     int nc = acc.nc;
     double mean_sum = acc.mean_sum, csum = acc.csum;
@@ -350,15 +356,22 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
       } else {  // full cycle, drop its two points -> stack = [..., p]
         tail -= 2;
         size -= 2;
+#ifdef FLEET_ABL_NO_POP_LOADS  // diagnostic: no stack reads / writes on a closure (wrong results)
+        b = a * 0.5;
+        a = 0.0;
+#else
         stk[tail - 1] = p;
         b = stk[tail - 2];                       // size >= 2 here
         a = (size >= 3) ? stk[tail - 3] : 0.0;
+#endif
       }
     }
     acc.nc = nc;
     acc.mean_sum = mean_sum;
     acc.csum = csum;
+#ifndef FLEET_ABL_NO_ACC_RMW
     *reinterpret_cast<RfAcc*>(row) = acc;
+#endif
   }
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
