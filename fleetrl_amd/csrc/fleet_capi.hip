@@ -267,6 +267,7 @@ void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabX>
     x.tb.sor = t.soc_on_return[k];
     x.tb.tl = t.time_left[k];
     x.tb.there = t.there[k];
+#ifndef FLEET_TAB16
     x.ar.tgt_th = x.ar.cl = x.ar.hn = x.ar.lax = 0.0f;
     if (!p.aux) continue;
     const double th = (double)t.there[k];
@@ -279,6 +280,7 @@ void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabX>
     x.ar.cl = (float)(norm ? cl / p.max_soc : cl);
     x.ar.hn = (float)(norm ? hn / p.max_hours_needed : hn);
     x.ar.lax = (float)(norm ? lax / p.max_laxity : lax);
+#endif
   }
 }
 
@@ -328,6 +330,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.penalty_overload = p->penalty_overloading; d.fully_charged_reward = p->fully_charged_reward;
   d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps;
   d.max_time_left = p->max_time_left;
+  d.batt_cap_nominal = p->batt_cap_nominal;
+  d.hn_denominator = p->evse_power * p->charging_eff;
 
   FleetCold& cd = b->cold_host;
   cd.min_laxity = p->min_laxity; cd.def_soc = p->def_soc; cd.init_soh = p->init_soh; cd.temperature = p->temperature;

@@ -50,10 +50,13 @@ struct AuxRec {
   float lax;     // laxity
 };
 
-// What a lane reads of (time row t, EV c): both records side by side, 32 B, one array / one pointer.
+// What a lane reads of (time row t, EV c).  Default: both records side by side, 32 B, one array / one pointer.  With
+// FLEET_TAB16 (experiment) the 16-byte table record alone: the auxiliary slots are recomputed per lane.
 struct TabX {
   TabRec tb;
+#ifndef FLEET_TAB16
   AuxRec ar;  // zeros when the auxiliary observations are off
+#endif
 };
 
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
@@ -163,6 +166,7 @@ struct FleetDev {
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
+  double batt_cap_nominal, hn_denominator;  // auxiliary observation slots (observer_*.py:88): nominal capacity, evse * eta_c
   // ---- read-only tables ---------------------------------------------------------------------------------
   const TabX* tab;            // [T,N]
   const PhysRow* tab_phys;    // [T]

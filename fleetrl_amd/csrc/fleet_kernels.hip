@@ -188,7 +188,7 @@ __device__ __forceinline__ void st_rec16(T* p, const T& v) {
 #endif
 }
 __device__ __forceinline__ TabX ld_tabx(const TabX* p) {
-#ifdef FLEET_NT_TAB
+#if defined(FLEET_NT_TAB) && !defined(FLEET_TAB16)
   typedef double v4d __attribute__((ext_vector_type(4)));
   const v4d raw = __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p));
   TabX out;
@@ -218,6 +218,32 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
   st_obs(a + c, (float)tb.there);
+#ifdef FLEET_TAB16
+  {
+    // the four table-derived auxiliary slots (observer_bl_pv.py:85-91, oracle_normalization.py:127-131) in the reference's own
+    // float64 operations -- the same the 32-byte layout tabulates on the host, so the float32 words are identical
+    const double th = (double)tb.there;
+    const double tgt_th = (t090 ? 0.9 : d.target_soc) * th;
+    const double cl = tgt_th - tb.sor;
+    const double hn = cl * d.batt_cap_nominal / d.hn_denominator;
+    double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
+    lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
+    if (d.normalize) {
+      const FleetCold* cd = d.cold;
+      st_obs(a + N + c, (float)(tgt_th / cd->max_soc));
+      st_obs(a + 2 * N + c, (float)(cl / cd->max_soc));
+      st_obs(a + 3 * N + c, (float)(hn / cd->max_hours_needed));
+      st_obs(a + 4 * N + c, (float)(lax / cd->max_laxity));
+    } else {
+      st_obs(a + N + c, (float)tgt_th);
+      st_obs(a + 2 * N + c, (float)cl);
+      st_obs(a + 3 * N + c, (float)hn);
+      st_obs(a + 4 * N + c, (float)lax);
+    }
+    (void)ar;
+    return;
+  }
+#endif
   if (!t090) {
     st_obs(a + N + c, ar.tgt_th);
     st_obs(a + 2 * N + c, ar.cl);
@@ -507,7 +533,11 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
     const TabX tx = d.tab[ti];
     const TabRec tb = tx.tb;
+#ifdef FLEET_TAB16
+    const AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
+#else
     const AuxRec ar = tx.ar;
+#endif
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
@@ -772,7 +802,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
       const TabX tx1 = ld_tabx(tab_t1 + c);  // the only per-lane load that depends on the time row: requested first
       const TabRec tb1 = tx1.tb;
+#ifdef FLEET_TAB16
+      const AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
+#else
       const AuxRec ar = tx1.ar;
+#endif
       // last logged SOC sample: the SOC itself unless it was frozen when the EV left (see struct Hot)
       // (requested unconditionally with the record itself: a load that depended on the record's FROZEN bit would add a
       // memory round trip to the chain of the lanes whose EV is away)
