@@ -95,13 +95,14 @@ def kernel_source_sha() -> str:
 def committed_traffic(config: str, envs: int, evs: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
     profiles/r02_traffic_<config>.json); None when the profile is absent, was taken on another kernel source or shape."""
-    path = os.path.join(ROOT, "profiles", f"r02_traffic_{config}.json")
-    if not os.path.isfile(path):
-        return None
-    t = json.load(open(path))
-    if t.get("kernel_src_sha") != kernel_source_sha() or (t.get("envs"), t.get("evs")) != (envs, evs):
-        return None
-    return t.get("hbm_bytes_per_launch")
+    for name in (f"r02_traffic_{config}.json", f"r02_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.isfile(path):
+            continue
+        t = json.load(open(path))
+        if t.get("kernel_src_sha") == kernel_source_sha() and (t.get("envs"), t.get("evs"), t.get("config")) == (envs, evs, config):
+            return t.get("hbm_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(params, tables, time_feat, n_evs: int, budget_s: float = 8.0):
