@@ -113,14 +113,15 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
-  // the rainflow stack indices travel in 13-bit fields of the hot record (fleet_device.h HOT_PACK)
-  if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps + 3 > FLEET_MAX_STACK_ROWS)
-    return "rainflow/SEI degradation: episode_steps + 3 exceeds 8191 (the packed rainflow stack indices are 13 bits wide)";
+  // the rainflow stack size travels in a 26-bit field of the hot record (fleet_device.h HOT_PACK)
+  if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
+    return "rainflow/SEI degradation: episode_steps exceeds 67 million (the packed rainflow stack size is 26 bits wide)";
+  if (p->table_rows >= 0x3FFFFFFF) return "table_rows exceeds 2^30 - 1 (segment ends are 30 bits wide)";
   if (t->finish_row)
     for (int r = 0; r < p->table_rows; ++r) {
       if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
-      if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r + 3 > FLEET_MAX_STACK_ROWS)
-        return "rainflow/SEI degradation: an episode spans more than 8188 rows (the packed rainflow stack indices are 13 bits wide)";
+      if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r > FLEET_MAX_STACK_ROWS - 3)
+        return "rainflow/SEI degradation: an episode spans more than 67 million rows (the packed rainflow stack size is 26 bits wide)";
     }
   if (t->lookahead_row)
     for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
@@ -253,34 +254,54 @@ void build_phys_rows(const FleetParams& p, const FleetTables& t, std::vector<Phy
   for (int r = 0; r < T; ++r) phys[r].flags_next = flags[r + 1 < T ? r + 1 : T - 1];
 }
 
-// Per-(t, EV) records (32 bytes): the three schedule columns packed into 16 bytes, and the five auxiliary observation
-// slots pre-assembled for the configured target SOC (observer_bl_pv.py:85-91 and, when normalising,
-// oracle_normalization.py:127-131) -- float64 in the reference's operation order, stored as the float32 words the
-// reference would emit.  `there` is kept in TabRec; the other four go to AuxRec.
-void build_ev_rows(const FleetParams& p, const FleetTables& t, std::vector<TabX>& tab) {
-  const size_t TN = (size_t)p.table_rows * p.num_cars;
-  tab.resize(TN);
-  const bool norm = p.normalize != 0;
-  const double hn_den = p.evse_power * p.charging_eff;
-  for (size_t k = 0; k < TN; ++k) {
-    TabX& x = tab[k];
-    x.tb.sor = t.soc_on_return[k];
-    x.tb.tl = t.time_left[k];
-    x.tb.there = t.there[k];
-#ifndef FLEET_TAB16
-    x.ar.tgt_th = x.ar.cl = x.ar.hn = x.ar.lax = 0.0f;
-    if (!p.aux) continue;
-    const double th = (double)t.there[k];
-    const double tgt_th = p.target_soc * th;
-    const double cl = tgt_th - t.soc_on_return[k];
-    const double hn = cl * p.batt_cap_nominal / hn_den;
-    double lax = ((double)t.time_left[k] / (hn + 0.001) - 1) * th;
-    lax = lax < 0 ? 0 : (lax > 5 ? 5 : lax);
-    x.ar.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
-    x.ar.cl = (float)(norm ? cl / p.max_soc : cl);
-    x.ar.hn = (float)(norm ? hn / p.max_hours_needed : hn);
-    x.ar.lax = (float)(norm ? lax / p.max_laxity : lax);
-#endif
+// Per-(t, EV) schedule records in run-length form (struct SegRec in fleet_device.h): consecutive rows of an EV with the same
+// There, the same SOC_on_return (bit for bit) and a time_left that counts down to the same departure row form a segment and
+// share one record.  Whether a row's float32 time_left is what the kernels derive from the departure row is checked here
+// with the kernels' own expression (seg_tl); a row where it is not -- an irregular time grid, a hand-made table -- becomes
+// a one-row segment that carries its time_left verbatim.
+void build_seg_rows(const FleetParams& p, const FleetTables& t, std::vector<SegRec>& seg) {
+  const int T = p.table_rows, N = p.num_cars;
+  seg.resize((size_t)T * N);
+  std::vector<uint8_t> raw((size_t)T);
+  std::vector<uint32_t> dep((size_t)T);
+  for (int c = 0; c < N; ++c) {
+    for (int r = 0; r < T; ++r) {
+      const float tl = t.time_left[(size_t)r * N + c];
+      raw[r] = 0;
+      dep[r] = 0;  // time_left == 0: no departure ahead
+      if (tl != 0.0f) {
+        const double k = (double)tl / p.dt;
+        const long long kk = std::llround(k);
+        SegRec probe;
+        probe.sor = 0.0;
+        probe.tlx = (uint32_t)(r + kk);
+        probe.se = 0;
+        if (!t.dt_row && kk >= 1 && (long long)r + kk < 0x3FFFFFFFll && seg_tl(probe, r, p.dt) == tl)
+          dep[r] = (uint32_t)(r + kk);
+        else
+          raw[r] = 1;
+      }
+    }
+    uint32_t end = (uint32_t)T;
+    for (int r = T - 1; r >= 0; --r) {
+      const size_t k = (size_t)r * N + c;
+      if (r < T - 1) {
+        const size_t k1 = k + N;
+        uint64_t s0, s1;
+        memcpy(&s0, &t.soc_on_return[k], 8);
+        memcpy(&s1, &t.soc_on_return[k1], 8);
+        const bool same = !raw[r] && !raw[r + 1] && t.there[k] == t.there[k1] && s0 == s1 && dep[r] == dep[r + 1];
+        if (!same) end = (uint32_t)(r + 1);
+      }
+      SegRec& x = seg[k];
+      x.sor = t.soc_on_return[k];
+      if (raw[r]) {
+        memcpy(&x.tlx, &t.time_left[k], 4);
+      } else {
+        x.tlx = dep[r];
+      }
+      x.se = end | (raw[r] ? SEG_RAW : 0u) | (t.there[k] ? 0x80000000u : 0u);
+    }
   }
 }
 
@@ -348,9 +369,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     build_phys_rows(*p, *t, phys, flags);
     std::vector<float> tail;
     build_tail_rows(*p, *t, d.tail_a_len, d.tail_b_len, d.tail_stride, tail);
-    std::vector<TabX> tab;
-    build_ev_rows(*p, *t, tab);
-    if ((rc = dev_upload(b, &d.tab, tab.data(), tab.size()))) return rc;
+    std::vector<SegRec> seg;
+    build_seg_rows(*p, *t, seg);
+    if ((rc = dev_upload(b, &d.seg, seg.data(), seg.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
@@ -382,6 +403,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   // ---- state ----------------------------------------------------------------------------------------
   const size_t EN = (size_t)E * N;
   if ((rc = dev_alloc(b, &d.hot, EN))) return rc;
+  if ((rc = dev_alloc(b, &d.run, EN))) return rc;
   if ((rc = dev_alloc(b, &d.soh, EN))) return rc;
   if ((rc = dev_alloc(b, &d.soc_deg, EN))) return rc;
   if ((rc = dev_alloc(b, &d.sei, EN))) return rc;

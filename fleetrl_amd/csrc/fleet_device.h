@@ -3,11 +3,13 @@
 //
 // Layout rules (DESIGN.md "Data layout in HBM"):
 //   * everything a lane reads AND writes every step sits in one dense 16-byte record per (env, EV): one 16-byte load /
-//     store per lane, consecutive lanes = consecutive records, whole cache lines; what changes rarely (soh, the frozen
-//     soc_deg of an absent EV) sits in planes of its own and is only written when it changes;
+//     store per lane, consecutive lanes = consecutive records, whole cache lines; what changes rarely (soh, the schedule
+//     record of the next row, the rainflow stack top) sits in planes of its own that are only written when it changes;
+//   * nothing a lane needs to start its arithmetic depends on the env's time row: the schedule columns of the next row
+//     travel with the state in run-length form (`run`, struct SegRec), so the per-(row, EV) table is only touched when
+//     an EV crosses a schedule event, and then for the row AFTER next -- off the step's critical path;
 //   * everything a group needs per env and step sits in ONE 64-byte record (16-byte head + leader statistics);
-//   * table values of (time row, EV) sit in one 32-byte record, the env-level observation blocks and the physics
-//     scalars of a time row in contiguous rows;
+//   * the env-level observation blocks and the physics scalars of a time row sit in contiguous rows;
 //   * rarely touched state (rainflow accumulators + stack, SEI model) sits in per-EV 128-byte-aligned rows / 32-byte
 //     records so an event touches one cache line and the hot path none.
 #pragma once
@@ -34,59 +36,67 @@ struct PhysRow {
                         // constant step on a regular grid, per row on an irregular one (real_time)
 };
 
-// Table record of (time row t, EV c), 16 B.
-struct TabRec {
-  double sor;      // db["SOC_on_return"]
-  float tl;        // db["time_left"] (multiple of dt, exact in f32)
-  uint32_t there;  // db["There"]
+// Schedule record of (time row t, EV c), 16 B: the three schedule columns of the row -- db["There"], db["time_left"],
+// db["SOC_on_return"] -- in run-length form.  Between two schedule events of an EV (departure, arrival, a change of
+// SOC_on_return at an hour boundary of the caretaker's lunch rule) `There` and `SOC_on_return` are constant and `time_left`
+// falls by dt per row, so consecutive rows form a SEGMENT and every row of a segment holds the SAME record: the two constant
+// columns, the departure row `time_left` counts down to, and the first row after the segment.  A lane that holds the record
+// of one row therefore holds the record of every row up to `seg_end` and only has to touch the table when it crosses a
+// segment boundary (about four times per EV and day).  Built by fleet_create (fleet_capi.hip build_seg_rows), which checks
+// row by row that the float32 `time_left` the table holds is exactly what `seg_tl` derives; a row where it is not (irregular
+// time grids, hand-made tables) becomes a one-row segment that carries its `time_left` verbatim (SEG_RAW).
+struct SegRec {
+  double sor;    // db["SOC_on_return"] of every row of the segment
+  uint32_t tlx;  // departure row `dep`: time_left(r) = (dep - r) * dt for r < dep, else 0; SEG_RAW: the float32 time_left itself
+  uint32_t se;   // [29:0] first row after the segment, [30] SEG_RAW, [31] db["There"]
 };
-
-// Pre-assembled auxiliary observation slots of (t, c) for the un-degraded target SOC, 16 B
-// (observer_bl_pv.py:85-91 + oracle_normalization.py:127-131), already normalised when normalize_in_env.
-struct AuxRec {
-  float tgt_th;  // target_soc * there
-  float cl;      // charging_left
-  float hn;      // hours_needed
-  float lax;     // laxity
-};
-
-// What a lane reads of (time row t, EV c).  Default: both records side by side, 32 B, one array / one pointer.  With
-// FLEET_TAB16 (experiment) the 16-byte table record alone: the auxiliary slots are recomputed per lane.
-struct TabX {
-  TabRec tb;
-#ifndef FLEET_TAB16
-  AuxRec ar;  // zeros when the auxiliary observations are off
-#endif
-};
+#define SEG_RAW 0x40000000u
+#define SEG_END(se) ((int)((se) & 0x3FFFFFFFu))
+#define SEG_THERE(se) ((se) >> 31)
+// db["time_left"] of row r from the record of r's segment (exact float32: checked row by row when the table was built)
+__host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
+  if (s.se & SEG_RAW) {
+    union { uint32_t u; float f; } v;
+    v.u = s.tlx;
+    return v.f;
+  }
+  const int left = (int)s.tlx - r;
+  return left > 0 ? (float)((double)left * dt) : 0.0f;
+}
 
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
 // ---- state ---------------------------------------------------------------------------------------------------
 // Hot state of (env e, EV c): ONE dense 16-byte record read and written every step (consecutive lanes = consecutive
-// records = whole cache lines), plus two float64 planes that are NOT written every step:
-//   soh     : read every step (battery_cap = soh * init_battery_cap), written on the daily degradation row only;
-//   soc_deg : episode.soc_deg == last logged SOC sample.  While an EV is plugged in it equals `soc` after every step
-//             (fleet_environment.py:621-623), so it is only materialised while it differs -- the EV is away (or the
-//             episode started from an empty battery, :395-399) -- and the FROZEN bit says so.  Written once per trip.
+// records = whole cache lines).  episode.soc and episode.soc_deg (the last logged SOC sample) share its float64 field:
+//   * while the EV is plugged in they are equal after every step (fleet_environment.py:621-623): x = soc = soc_deg;
+//   * while it is away (hours_left == 0) soc_deg keeps its last value and soc is the table's SOC_on_return of an empty
+//     slot, i.e. +0.0: FROZEN, x = soc_deg and soc = 0.0 is implied;
+//   * the one combination that does not fit -- away-like state with a non-zero soc (the rows after an EV's last departure
+//     of the table, hand-made tables) or a reset that starts from soc == -0.0 -- keeps x = soc and puts soc_deg into the
+//     soc_deg plane: FROZEN | INPLANE (read through a dependent load; it does not occur inside the reference's episodes).
+// Everything else that changes rarely has planes of its own that are only written when it changes: `soh` (daily), the
+// schedule record of the next row `run` (at schedule events), the rainflow stack top `rf_top` (when a reversal is pushed).
 struct Hot {
-  double soc;      // episode.soc
+  double x;        // episode.soc and / or episode.soc_deg, see above
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
-  uint32_t bits;   // [12:0] rainflow stack tail, [25:13] stack head, [27:26] sign of the last SOC slope
-                   // (0 none, 1 up, 2 down), [28] FROZEN: soc_deg lives in the soc_deg plane (else soc_deg == soc),
-                   // [30] There at the current time row (carried so the step needs no table read for it),
-                   // [31] sticky "target_soc = 0.9" flag (quirk Q7)
+  uint32_t bits;   // [25:0] rainflow stack size (the stack always starts at slot 0), [26] INPLANE, [28:27] sign of the last
+                   // SOC slope (0 none, 1 up, 2 down), [29] FROZEN, [30] There at the current time row (carried so the
+                   // step needs no table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
-#define HOT_TAIL(b) ((int)((b) & 0x1FFFu))
-#define HOT_HEAD(b) ((int)(((b) >> 13) & 0x1FFFu))
-#define HOT_SGN(b) ((int)(((b) >> 26) & 3u))
-#define HOT_FROZEN(b) ((((b) >> 28) & 1u) != 0u)
+#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFFu))
+#define HOT_INPLANE(b) ((((b) >> 26) & 1u) != 0u)
+#define HOT_SGN(b) ((int)(((b) >> 27) & 3u))
+#define HOT_FROZEN(b) ((((b) >> 29) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define FLEET_MAX_STACK_ROWS 8191  // 13-bit tail / head: fleet_create rejects longer episodes in rainflow mode
-#define HOT_PACK(tail, head, sgn, frozen, there, t090)                                                                     \
-  (((uint32_t)(tail) & 0x1FFFu) | (((uint32_t)(head) & 0x1FFFu) << 13) | (((uint32_t)(sgn) & 3u) << 26) |                \
-   ((frozen) ? 0x10000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
+#define FLEET_MAX_STACK_ROWS 0x3FFFFFF  // 26-bit stack size: 67 million samples per episode
+#define HOT_PACK(tail, sgn, frozen, inplane, there, t090)                                                                 \
+  (((uint32_t)(tail) & 0x3FFFFFFu) | ((inplane) ? 0x4000000u : 0u) | (((uint32_t)(sgn) & 3u) << 27) |                    \
+   ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
+// episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
+#define HOT_SOC(h) ((HOT_FROZEN((h).bits) && !HOT_INPLANE((h).bits)) ? 0.0 : (h).x)
 
 // Env record, 64 B = one cache line: the 16-byte head every lane of the group needs (wave-uniform for G == 64),
 // followed by the episode statistics only the group's leader lane touches.  One pointer, one line per env and step
@@ -168,7 +178,7 @@ struct FleetDev {
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
   double batt_cap_nominal, hn_denominator;  // auxiliary observation slots (observer_*.py:88): nominal capacity, evse * eta_c
   // ---- read-only tables ---------------------------------------------------------------------------------
-  const TabX* tab;            // [T,N]
+  const SegRec* seg;          // [T,N] schedule records in run-length form
   const PhysRow* tab_phys;    // [T]
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]
@@ -177,8 +187,10 @@ struct FleetDev {
   const struct FleetDev* self;  // device-resident copy of this block: the out-of-line rare paths read it from memory
   // ---- state ------------------------------------------------------------------------------------------
   Hot* hot;           // [E,N]
+  SegRec* run;        // [E,N] schedule record of row t+1 (the row the next step advances to); rewritten when t+2 crosses a
+                      // segment boundary, i.e. at schedule events only
   double* soh;        // [E,N]
-  double* soc_deg;    // [E,N] (valid where the FROZEN bit is set)
+  double* soc_deg;    // [E,N] (valid where the INPLANE bit is set)
   RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]

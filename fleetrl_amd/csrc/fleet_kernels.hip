@@ -19,6 +19,12 @@
 // episode end, sample count) redundantly in registers, so nothing written by one lane is re-read by another
 // inside a launch.  No MFMA: there is no contraction on this path.
 //
+// Schedule columns in run-length form.  What a step needs of the (time row, EV) table -- There, time_left, SOC_on_return of
+// the row it advances to -- travels with the state (`run`, struct SegRec in fleet_device.h): a lane holds the record of row
+// t+1 when the launch starts, so nothing it needs to start its arithmetic depends on the env's time row, and it only touches
+// the table when row t+2 crosses a schedule event of its EV (about 4 % of the EV-steps), for the NEXT launch.  The five
+// auxiliary observation slots are computed from that record in the reference's own float64 operations.
+//
 // Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
 // simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (reversal
 // stack in HBM, top two entries cached, slope sign, closed-cycle count, sum of cycle means, stress sum of the
@@ -62,8 +68,8 @@ namespace {
 // Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The
 // single-step kernel needs 97 VGPRs; the multi-step kernel 124-126, i.e. it also runs 4 waves per SIMD although it is only
 // asked for 2 (asking for 3 or 4 makes the register allocator spill a little and is slower).
-// Other FLEET_* macros in this file (FLEET_ABL_*, FLEET_NT_*, FLEET_STAMPS, FLEET_OBS_EVERY_STEP) are diagnostics for
-// tools/ab_build.sh and never defined in the product build.
+// Other FLEET_* macros in this file (FLEET_ABL_EMPTY, FLEET_STAMPS) are diagnostics for tools/ab_build.sh and never defined
+// in the product build.
 #ifndef FLEET_SINGLE_WAVES
 #define FLEET_SINGLE_WAVES 4
 #endif
@@ -151,108 +157,55 @@ __device__ __forceinline__ double overloading_penalty(double rel, double scale) 
 // ---------------------------------------------------------------------------------------------------------
 // observation assembly (observer_*.py + normalization/*.py); layout: DESIGN.md "Observation row"
 // ---------------------------------------------------------------------------------------------------------
-// Auxiliary slots of an EV whose target SOC has been raised to 0.9 (quirk Q7): computed on the fly
-// (observer_bl_pv.py:85-91, oracle_normalization.py:127-131).  Rare, kept out of line.
-__device__ __forceinline__ void write_obs_aux_raised_target(const FleetDev& d, float* __restrict__ a, int c, const TabRec& tb) {
-  const int N = d.N;
-  const FleetCold* cd = d.cold;
-  const double th = (double)tb.there;
-  const double tgt_th = 0.9 * th;
-  const double cl = tgt_th - tb.sor;
-  const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
-  double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
-  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-  if (cd->normalize) {
-    a[N + c] = (float)(tgt_th / cd->max_soc);
-    a[2 * N + c] = (float)(cl / cd->max_soc);
-    a[3 * N + c] = (float)(hn / cd->max_hours_needed);
-    a[4 * N + c] = (float)(lax / cd->max_laxity);
-  } else {
-    a[N + c] = (float)tgt_th;
-    a[2 * N + c] = (float)cl;
-    a[3 * N + c] = (float)hn;
-    a[4 * N + c] = (float)lax;
-  }
-}
-
-// Streaming (non-temporal) stores / loads for data the launch touches exactly once: they do not linger dirty in the
-// write-back L2 until the end-of-kernel release has to flush them.
-typedef double fleet_v2d __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ void st_rec16(T* p, const T& v) {
   static_assert(sizeof(T) == 16, "16-byte record");
-#ifdef FLEET_NT_STATE
-  __builtin_nontemporal_store(*reinterpret_cast<const fleet_v2d*>(&v), reinterpret_cast<fleet_v2d*>(p));
-#else
   *p = v;
-#endif
 }
-__device__ __forceinline__ TabX ld_tabx(const TabX* p) {
-#if defined(FLEET_NT_TAB) && !defined(FLEET_TAB16)
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  const v4d raw = __builtin_nontemporal_load(reinterpret_cast<const v4d*>(p));
-  TabX out;
-  __builtin_memcpy(&out, &raw, sizeof(TabX));
-  return out;
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void st_obs(float* p, float v) {
-#ifdef FLEET_NT_OBS
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+__device__ __forceinline__ void st_obs(float* p, float v) { *p = v; }
+
+// The three schedule columns of one (row, EV), decoded from the record of the row's segment.
+struct RowRec {
+  double sor;      // db["SOC_on_return"]
+  float tl;        // db["time_left"]
+  uint32_t there;  // db["There"]
+};
+__device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
+  RowRec o;
+  o.sor = s.sor;
+  o.tl = seg_tl(s, r, dt);
+  o.there = SEG_THERE(s.se);
+  return o;
 }
 
-// Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the
-// step advanced to (quirk Q10) -- pre-assembled on the host for the configured target SOC (AuxRec `ar`, loaded
-// by the caller together with the table record), recomputed here only for an EV whose target has been raised to
-// 0.9 (quirk Q7).
+// Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the step
+// advanced to (quirk Q10), in the reference's own float64 operations (observer_bl_pv.py:85-91, oracle_normalization.py:
+// 127-131) for the EV's target SOC (raised to 0.9 by quirk Q7 or not).
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
-                                             const TabRec& tb, const AuxRec& ar) {
+                                             const RowRec& tb) {
   const int N = d.N;
   st_obs(row + c, (float)soc);
   st_obs(row + N + c, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
   st_obs(a + c, (float)tb.there);
-#ifdef FLEET_TAB16
-  {
-    // the four table-derived auxiliary slots (observer_bl_pv.py:85-91, oracle_normalization.py:127-131) in the reference's own
-    // float64 operations -- the same the 32-byte layout tabulates on the host, so the float32 words are identical
-    const double th = (double)tb.there;
-    const double tgt_th = (t090 ? 0.9 : d.target_soc) * th;
-    const double cl = tgt_th - tb.sor;
-    const double hn = cl * d.batt_cap_nominal / d.hn_denominator;
-    double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
-    lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-    if (d.normalize) {
-      const FleetCold* cd = d.cold;
-      st_obs(a + N + c, (float)(tgt_th / cd->max_soc));
-      st_obs(a + 2 * N + c, (float)(cl / cd->max_soc));
-      st_obs(a + 3 * N + c, (float)(hn / cd->max_hours_needed));
-      st_obs(a + 4 * N + c, (float)(lax / cd->max_laxity));
-    } else {
-      st_obs(a + N + c, (float)tgt_th);
-      st_obs(a + 2 * N + c, (float)cl);
-      st_obs(a + 3 * N + c, (float)hn);
-      st_obs(a + 4 * N + c, (float)lax);
-    }
-    (void)ar;
-    return;
-  }
-#endif
-  if (!t090) {
-    st_obs(a + N + c, ar.tgt_th);
-    st_obs(a + 2 * N + c, ar.cl);
-    st_obs(a + 3 * N + c, ar.hn);
-    st_obs(a + 4 * N + c, ar.lax);
+  const double th = (double)tb.there;
+  const double tgt_th = (t090 ? 0.9 : d.target_soc) * th;
+  const double cl = tgt_th - tb.sor;
+  const double hn = cl * d.batt_cap_nominal / d.hn_denominator;
+  double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
+  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
+  if (d.normalize) {
+    const FleetCold* cd = d.cold;
+    st_obs(a + N + c, (float)(tgt_th / cd->max_soc));
+    st_obs(a + 2 * N + c, (float)(cl / cd->max_soc));
+    st_obs(a + 3 * N + c, (float)(hn / cd->max_hours_needed));
+    st_obs(a + 4 * N + c, (float)(lax / cd->max_laxity));
   } else {
-#ifndef FLEET_ABL_NO_RARE
-    write_obs_aux_raised_target(*d.self, a, c, tb);
-#endif
+    st_obs(a + N + c, (float)tgt_th);
+    st_obs(a + 2 * N + c, (float)cl);
+    st_obs(a + 3 * N + c, (float)hn);
+    st_obs(a + 4 * N + c, (float)lax);
   }
 }
 
@@ -337,9 +290,6 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
   double eff = rng * count;
   eff = eff > 1.0 ? 1.0 : eff;
   if (!(eff > 0.0)) return 0.0;  // pow(0, -0.501) = inf -> 1/inf = 0
-#ifdef FLEET_ABL_NO_STRESS
-  return eff * mean * stress_temp;
-#endif
   const double s_dod = 1.0 / (1.4E5 * pow_m0501(eff) + -1.23E5);   // (kd1 * dod**kd2 + kd3) ** -1
   const double s_soc = exp_small(1.04 * (mean - 0.5));              // e ** (k_sigma * (soc - sigma_ref)), |arg| <= 0.55
   return s_dod * s_soc * stress_temp;
@@ -347,8 +297,11 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
 
 // A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
 // three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
-// Stack column `stk` (row stride EN); its top two entries travel in registers (`top`, from the RfTop record).
-__device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, int& head, RfTop& top, uint32_t& err) {
+// The stack of the EV lives in its rainflow row behind the RfAcc header and always starts at slot 0 (`tail` = its
+// size; when the three-point rule drops the FIRST point -- the stack is exactly [a, b, p] then -- the two survivors are
+// rewritten to slots 0 and 1, so no head index exists and the size alone describes it); its top two entries travel in
+// registers (`top`, from the RfTop record).
+__device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, RfTop& top, uint32_t& err) {
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
   double* stk = row + 4;  // the stack follows the RfAcc header in the same 128-byte-aligned row
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
@@ -356,48 +309,34 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
     return;
   }
   double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
-#ifndef FLEET_ABL_NO_STK_STORE
   stk[tail] = p;
-#endif
-  tail += 1;
-  int size = tail - head;  // >= 2: the episode's first sample is always on the stack
-  if (size >= 3 && !(fabs(p - b) < fabs(b - a))) {
-#ifdef FLEET_ABL_NO_ACC_RMW  // diagnostic: no accumulator line traffic (wrong results)
-    RfAcc acc = {0.0, 0.0, 0, 1000, 0.0};
-#else
+  tail += 1;  // >= 2: the episode's first sample is always on the stack
+  if (tail >= 3 && !(fabs(p - b) < fabs(b - a))) {
     RfAcc acc = *reinterpret_cast<RfAcc*>(row);
-#endif
     const int L = acc.rf_len;
     int nc = acc.nc;
     double mean_sum = acc.mean_sum, csum = acc.csum;
-    while (size >= 3) {
+    while (tail >= 3) {
       const double X = fabs(p - b), Y = fabs(b - a);
       if (X < Y) break;
-      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.self->stress_temp);
+      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
       mean_sum += 0.5 * (a + b);
       nc += 1;
-      if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
-        head += 1;
-        size = 2;
+      if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
+        stk[0] = b;
+        stk[1] = p;
+        tail = 2;
       } else {  // full cycle, drop its two points -> stack = [..., p]
         tail -= 2;
-        size -= 2;
-#ifdef FLEET_ABL_NO_POP_LOADS  // diagnostic: no stack reads / writes on a closure (wrong results)
-        b = a * 0.5;
-        a = 0.0;
-#else
         stk[tail - 1] = p;
-        b = stk[tail - 2];                       // size >= 2 here
-        a = (size >= 3) ? stk[tail - 3] : 0.0;
-#endif
+        b = stk[tail - 2];                       // tail >= 2 here
+        a = (tail >= 3) ? stk[tail - 3] : 0.0;
       }
     }
     acc.nc = nc;
     acc.mean_sum = mean_sum;
     acc.csum = csum;
-#ifndef FLEET_ABL_NO_ACC_RMW
     *reinterpret_cast<RfAcc*>(row) = acc;
-#endif
   }
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
@@ -407,11 +346,10 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
 // `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, int head, const RfTop& top, uint32_t& err,
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, const RfTop& top, uint32_t& err,
                                              double dt_hours) {
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
   const double* stk = row + 4;
-  const FleetCold* cd = d.cold;
   // everything this needs from memory is requested up front (one round trip)
   RfAcc acc = *reinterpret_cast<RfAcc*>(row);
   SeiRec sr = d.sei[i];
@@ -440,7 +378,7 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     nv += 1;
   };
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
-    int vt = tail, vh = head;
+    int vt = tail, vh = 0;
     int size = vt - vh + 1;
     double a = top.s1, b = top.s2;
     while (size >= 3) {
@@ -512,6 +450,28 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
   return cal + cyc;
 }
 
+// The hot record of an EV whose soc / soc_deg / hours_left are given (struct Hot in fleet_device.h): the shared float64
+// field, the FROZEN / INPLANE flags, and the soc_deg plane entry in the one case that needs it.  `plane_has` = the
+// plane already holds this soc_deg (the EV was INPLANE before and soc_deg has not changed since).
+__device__ __forceinline__ Hot hot_encode(const FleetDev& d, size_t i, double soc, double soc_deg, float hl, int tail, int sgn,
+                                          uint32_t there, bool t090, bool plane_has) {
+  Hot h;
+  h.hl = hl;
+  bool frozen = false, inplane = false;
+  h.x = soc;
+  if (__double_as_longlong(soc_deg) != __double_as_longlong(soc)) {
+    frozen = true;
+    if (__double_as_longlong(soc) == 0ll) {
+      h.x = soc_deg;  // soc == +0.0 is implied
+    } else {
+      inplane = true;
+      if (!plane_has) d.soc_deg[i] = soc_deg;
+    }
+  }
+  h.bits = HOT_PACK(tail, sgn, frozen, inplane, there, t090);
+  return h;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
@@ -520,7 +480,6 @@ template <int G, bool LOG>
 __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
   const bool log_on = LOG && (d.log_pos != nullptr);
   const int N = d.N;
-  const size_t EN = (size_t)d.E * N;
   const FleetCold* cd = d.cold;
   const int start = choose_start(cd, d.E, e, r.episodes);
   r.t = start;
@@ -529,15 +488,12 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   // data log: the row reset() writes -- time, observation and SoH, zeros for everything else (:420-432)
   const size_t lrow = log_on ? (size_t)(lp % d.log_cap) * d.E + e : 0;
   float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
+  const int next = start + 1 > d.T - 1 ? d.T - 1 : start + 1;
   for (int c = g; c < N; c += G) {
-    const size_t i = (size_t)e * N + c, ti = (size_t)start * N + c;
-    const TabX tx = d.tab[ti];
-    const TabRec tb = tx.tb;
-#ifdef FLEET_TAB16
-    const AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
-#else
-    const AuxRec ar = tx.ar;
-#endif
+    const size_t i = (size_t)e * N + c;
+    const SegRec s0 = d.seg[(size_t)start * N + c];
+    const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
+    const RowRec tb = seg_row(s0, start, d.dt);
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
     const double cap = soh * d.init_cap;
@@ -548,14 +504,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    const bool frozen = (soc_deg != soc);
-    Hot h;
-    h.soc = soc;
-    h.hl = hl;
-    h.bits = HOT_PACK(1, 0, 0, frozen, tb.there, t090);  // rainflow: the first sample is the first reversal point
-    d.hot[i] = h;
+    d.hot[i] = hot_encode(d, i, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
+    d.run[i] = s1;
     d.soh[i] = soh;
-    if (frozen) d.soc_deg[i] = soc_deg;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
       double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
       RfTop top;
@@ -569,9 +520,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       *reinterpret_cast<RfAcc*>(row) = acc;
       row[4] = soc_deg;
     }
-    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
+    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb);
     if (log_on) {
-      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb, ar);
+      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb);
       double* lev = d.log_ev + lrow * 4 * N + c;
       lev[0] = 0.0;
       lev[N] = 0.0;
@@ -645,23 +596,22 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   if (G == 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
   const bool env_ok = e_raw < E_;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
   const int e = env_ok ? e_raw : E_ - 1;
-  const size_t EN = (size_t)d.E * N;
 
-  // One launch = one step and one EV per lane (N <= G): the lane's state records and its action do not depend on the
-  // env's time row, so they are requested before the env record is even read -- their latency then overlaps the
-  // env record -> time row -> table record chain instead of following it.
+  // One launch = one step and one EV per lane (N <= G): everything the lane needs to start its arithmetic -- its state
+  // records, the schedule record of the row the step advances to, its action -- has an address that does not depend on
+  // the env's time row, so it is requested before the env record is even read.
   constexpr bool kEarly = !MULTI && !WIDE;
   Hot h_pre = {0.0, 0.0f, 0u};
+  SegRec run_pre = {0.0, 0u, 0u};
   double soh_pre = 0.0;
-  double deg_pre = 0.0;
   RfTop top_pre = {0.0, 0.0};
   float a32_pre = 0.0f;
   double a64_pre = 0.0;
   if (kEarly && g < N) {
     const size_t i0 = (size_t)e * N + g;
     h_pre = p_hot[i0];
+    run_pre = d.run[i0];
     soh_pre = p_soh[i0];
-    deg_pre = d.soc_deg[i0];
     if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
     if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)p_actions)[i0];
     else a32_pre = ((const float*)p_actions)[i0];
@@ -685,11 +635,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   uint32_t err = 0;
   double reward_sum = 0.0;
   int n_done = 0;
-#ifdef FLEET_ABL_OBS_LOCAL  // diagnostic: same store instructions, (almost) no write traffic
-  float* const obs_row = obs + (size_t)(e & 63) * d.obs_dim;
-#else
   float* const obs_row = obs + (size_t)e * d.obs_dim;
-#endif
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
   const int steps = MULTI ? K : 1;
   const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
@@ -717,25 +663,22 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     const int t = r.t;
     int t1 = t + 1;  // :508
     if (t1 > d.T - 1) { t1 = d.T - 1; err |= FLEET_DEVERR_TABLE_END; }
+    const int t2 = t1 + 1 > d.T - 1 ? d.T - 1 : t1 + 1;  // the row the NEXT step advances to
     const bool is_done = (t + 1 == r.t_end);  // :627-628
     const bool resets = is_done && d.auto_reset;
     // where this step's observation goes: with vec-env auto-reset the terminal observation is reported aside
     float* const step_row = resets ? term_row : obs_row;
     // intermediate steps of a K-step launch only need their observation when the episode ends (terminal observation)
-#ifdef FLEET_OBS_EVERY_STEP
-    const bool write_step_obs = env_ok && (step_row != nullptr);
-#else
     const bool write_step_obs = env_ok && (step_row != nullptr) && (!MULTI || rt || resets || k == steps - 1);
-#endif
 
     FLEET_STAMP(1);
-    // ---- stage 2 loads: everything that depends on the time row, requested together -------------------------------
-    // The 64-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
+    // ---- loads that depend on the time row: the row's physics scalars and observation tail -----------------------------
+    // The 72-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
     // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
     // (not in rainflow mode, where vector registers are the scarcer resource)
     const PhysRow ph = d.tab_phys[t + (DEG == FLEET_DEG_RAINFLOW ? 0 : vzero)];
     // hours this step spans: `get_next_dt` (:455, :994-1008) -- a constant unless the grid is irregular (real_time only)
-    const double dt_step = ph.dt;
+    const double dt_step = rt ? ph.dt : d.dt;
     const uint32_t flags1 = ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
@@ -743,11 +686,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // launch's duration: they get issue priority over their SIMD's other wavefronts for the step itself (-3 % per launch)
     if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
     const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
-#ifdef FLEET_ABL_TAB_LOCAL  // diagnostic: same loads, table rows of 64 time steps only (cache resident)
-    const TabX* __restrict__ tab_t1 = d.tab + (size_t)(t1 & 63) * N;
-#else
-    const TabX* __restrict__ tab_t1 = d.tab + (size_t)t1 * N;
-#endif
 
     // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
     // buffer, so K-step launches log every step although they only return the last observation
@@ -790,28 +728,28 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // what the daily SEI pass needs of the lane's EV, carried in registers when a lane owns one EV (no reload round trip for
     // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
     double sei_sample = 0.0, sei_soh = 0.0;
-    int sei_tail = 0, sei_head = 0;
+    int sei_tail = 0;
     RfTop sei_top = {0.0, 0.0};
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
       const Hot hb = kEarly ? h_pre : d.hot[i];
+      const SegRec rr = kEarly ? run_pre : d.run[i];  // schedule record of row t1
       const double soh0 = kEarly ? soh_pre : d.soh[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
-      const TabX tx1 = ld_tabx(tab_t1 + c);  // the only per-lane load that depends on the time row: requested first
-      const TabRec tb1 = tx1.tb;
-#ifdef FLEET_TAB16
-      const AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
-#else
-      const AuxRec ar = tx1.ar;
-#endif
-      // last logged SOC sample: the SOC itself unless it was frozen when the EV left (see struct Hot)
-      // (requested unconditionally with the record itself: a load that depended on the record's FROZEN bit would add a
-      // memory round trip to the chain of the lanes whose EV is away)
-      const double deg_mem = kEarly ? deg_pre : d.soc_deg[i];
-      const double old_deg = HOT_FROZEN(hb.bits) ? deg_mem : hb.soc;
+      // the schedule record of the row AFTER next, for the next launch: only when that row starts a new segment of the EV's
+      // schedule (a departure, an arrival, ...).  Nothing in this step waits for it except the store at its very end.
+      const bool crosses = (t1 + 1 >= SEG_END(rr.se));
+      SegRec nr = rr;
+      if (crosses) nr = d.seg[(size_t)t2 * N + c];
+      const RowRec tb1 = seg_row(rr, t1, d.dt);
+      // last logged SOC sample: shares the record's float64 field with the SOC (struct Hot); the soc_deg plane only holds
+      // it in a combination that does not occur inside the reference's episodes (dependent load, INPLANE)
+      const bool inplane = HOT_INPLANE(hb.bits);
+      double old_deg = hb.x;
+      if (inplane) old_deg = d.soc_deg[i];
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -822,7 +760,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         } else {
           // benchmarking/distributed_charging.py:50-54: clip(get_dist_factor(), 0, 1), get_dist_factor =
           // hours_needed / (hours_left + 0.001) from the TABLE row of the current time (fleet_environment.py:782-799)
-          const TabRec tb0 = d.tab[(size_t)t * N + c].tb;
+          const RowRec tb0 = seg_row(d.seg[(size_t)t * N + c], t, d.dt);
           const FleetCold* cd = d.cold;
           const double th0 = (double)tb0.there;
           const double cl0 = (HOT_T090(hb.bits) ? 0.9 : d.target_soc) * th0 - tb0.sor;
@@ -839,7 +777,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
-      double soc = hb.soc;
+      double soc = HOT_SOC(hb);
       float hl = hb.hl;
       const double cap = soh0 * d.init_cap;
       bool t090 = HOT_T090(hb.bits);
@@ -899,23 +837,23 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
-#ifndef FLEET_ABL_NO_OBS
-      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
-      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1, ar);
-#endif
+      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1);
+      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1);
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      int tail = HOT_TAIL(hb.bits), head = HOT_HEAD(hb.bits), sgn = HOT_SGN(hb.bits);
+      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+      bool pushed = false;
       double soh = soh0;
       if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
         // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes
         // the previous sample a reversal point
         if (soc_deg != old_deg) {
           const int s_next = (soc_deg > old_deg) ? 1 : 2;
-#ifndef FLEET_ABL_NO_PUSH
-          if (sgn != 0 && sgn != s_next) rf_push(d, i, old_deg, tail, head, top, err);
-#endif
+          if (sgn != 0 && sgn != s_next) {
+            rf_push(d, i, old_deg, tail, top, err);
+            pushed = true;
+          }
           sgn = s_next;
         }
       }
@@ -924,7 +862,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         sei_sample = soc_deg;
         sei_soh = soh0;
         sei_tail = tail;
-        sei_head = head;
         sei_top = top;
       }
       if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
@@ -937,35 +874,26 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
       FLEET_STAMP(5);
       if (env_ok) {
-        // soc_deg == soc whenever the EV has hours left; otherwise it keeps its previous value, which has to be
-        // materialised the first time that happens (the EV just left) and stays where it is afterwards
-        const bool frozen = (hl == 0.0f);
-        if (frozen && !HOT_FROZEN(hb.bits)) d.soc_deg[i] = old_deg;
-        Hot nh;  // the whole 16-byte record, always: dense full-line stores
-        nh.soc = soc;
-        nh.hl = hl;
-        nh.bits = HOT_PACK(tail, head, sgn, frozen, tb1.there, t090);
-        st_rec16(d.hot + i, nh);
+        // the whole 16-byte record, always: dense full-line stores.  soc_deg == soc whenever the EV has hours left;
+        // otherwise it keeps its previous value, which shares the record's float64 field with an empty slot's soc == 0
+        st_rec16(d.hot + i, hot_encode(d, i, soc, soc_deg, hl, tail, sgn, tb1.there, t090, inplane));
+        if (crosses) st_rec16(d.run + i, nr);  // the next launch advances into another segment of the EV's schedule
         if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
-        // the cached stack top only changes when a reversal point was pushed (then tail and/or head moved)
-        if (DEG == FLEET_DEG_RAINFLOW && (tail != HOT_TAIL(hb.bits) || head != HOT_HEAD(hb.bits))) st_rec16(d.rf_top + i, top);
+        // the cached stack top only changes when a reversal point was pushed
+        if (DEG == FLEET_DEG_RAINFLOW && pushed) st_rec16(d.rf_top + i, top);
       }
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
-#ifndef FLEET_ABL_NO_OBS
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
     if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
-#endif
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
-#ifndef FLEET_ABL_NO_REDUCE
     cash = group_sum_to_last<G>(cash);
     rew = group_sum_to_last<G>(rew);
     asum = group_sum_to_last<G>(asum);
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
-#endif
     if (log_on) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
@@ -1004,26 +932,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers.  One step in 96, and wave-uniform for
     // G == 64.
-#if defined(FLEET_ABL_NO_EVAL) || defined(FLEET_ABL_NO_RARE)
-    if (false) {
-#else
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
-#endif
       for (int c = g; c < N; c += G) {
         const size_t i = (size_t)e * N + c;
         double deg, soh_new;
-#ifdef FLEET_ABL_SEI_RELOAD  // diagnostic: the round-1 form (always re-read)
-        if (false) {
-#else
         if (!WIDE) {
-#endif
-          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_head, sei_top, err, dt_step);
+          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, err, dt_step);
           soh_new = sei_soh - deg;
         } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
-          const double sample = HOT_FROZEN(hb.bits) ? d.soc_deg[i] : hb.soc;
+          const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
           const RfTop top = d.rf_top[i];
-          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), HOT_HEAD(hb.bits), top, err, dt_step);
+          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), top, err, dt_step);
           soh_new = d.soh[i] - deg;
         }
         d.soh[i] = soh_new;
@@ -1036,11 +956,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
     }
     if (logs) lp += 1;
-#ifdef FLEET_ABL_NO_RARE
-    if (false) {
-#else
     if (is_done) {
-#endif
       n_done += 1;
       if (leader && env_ok) {
         EnvRec* er = d.env + e;
@@ -1096,7 +1012,8 @@ __global__ void fleet_dist_factor_kernel(FleetDev d, double* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)d.E * d.N) return;
   const int e = (int)(i / d.N), c = (int)(i % d.N);
-  const TabRec tb = d.tab[(size_t)d.env[e].h.t * d.N + c].tb;
+  const int t = d.env[e].h.t;
+  const RowRec tb = seg_row(d.seg[(size_t)t * d.N + c], t, d.dt);
   const double th = (double)tb.there;
   const double tgt = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc;
   const double cl = tgt * th - tb.sor;
@@ -1113,10 +1030,10 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
                        field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
-    case FLEET_F_SOC: ((double*)out)[i] = d.hot[i].soc; break;
+    case FLEET_F_SOC: ((double*)out)[i] = HOT_SOC(d.hot[i]); break;
     case FLEET_F_HOURS_LEFT: ((float*)out)[i] = d.hot[i].hl; break;
     case FLEET_F_SOH: ((double*)out)[i] = d.soh[i]; break;
-    case FLEET_F_SOC_DEG: ((double*)out)[i] = HOT_FROZEN(d.hot[i].bits) ? d.soc_deg[i] : d.hot[i].soc; break;
+    case FLEET_F_SOC_DEG: ((double*)out)[i] = HOT_INPLANE(d.hot[i].bits) ? d.soc_deg[i] : d.hot[i].x; break;
     case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc; break;
     case FLEET_F_RF_LEN:
       ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfAcc*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;

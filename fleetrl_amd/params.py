@@ -57,9 +57,6 @@ def validate_supported(rc: ResolvedConfig) -> None:
     if rc.deg_mode == DEG_RAINFLOW and rc.init_soh != 1.0:
         raise ValueError("rainflow/SEI degradation with init_soh != 1.0 is ill-defined in the reference "
                          "(rainflow_sei_degradation.py:184); unsupported")
-    if rc.deg_mode == DEG_RAINFLOW and rc.episode_length * (60 // rc.minutes if 60 % rc.minutes == 0 else 1) + 3 > 8191:
-        raise ValueError("rainflow/SEI degradation: episodes longer than 8188 steps are not supported (the streaming rainflow's "
-                         "packed stack indices are 13 bits wide; fleet_create rejects them too)")
     if 60 % rc.minutes:
         raise ValueError("minutes per step must divide 60")
 

@@ -167,21 +167,24 @@ def _create_status(p, tables, time_feat):
     return rc, msg
 
 
-def test_create_rejects_episodes_longer_than_the_packed_stack_indices():
-    """The rainflow stack indices travel in 13-bit fields of the hot record: an episode of more than 8188 steps (85 days at
-    15 min) would overflow them silently -- rejected by fleet_create and, with a clear message, by the config layer."""
+def test_create_accepts_long_episodes_in_rainflow_mode():
+    """The reference accepts any `episode_length` (time_config.py:1-24, fleet_environment.py:355).  The rainflow stack size
+    travels in a 26-bit field of the hot record, so only episodes beyond 67 million steps are rejected (round 2 stopped at
+    8188 steps = 85 days); the config layer has no limit of its own any more."""
     g = load_trace("ct5_both_rainflow")
     p = params_for(g)
-    p.episode_steps = 8189
+    p.episode_steps = 24 * 4 * 365  # a whole year at 15 min: the status then only depends on the device
     rc, msg = _create_status(p, g.tables, g.time_feat)
-    assert rc == _capi.ERR_INVALID and "8191" in msg
-    p.deg_mode = _capi.DEG_LINEAR  # no stack: any length goes (the status then only depends on the device)
+    assert rc != _capi.ERR_INVALID, msg
+    p.episode_steps = (1 << 26) - 2
+    rc, msg = _create_status(p, g.tables, g.time_feat)
+    assert rc == _capi.ERR_INVALID and "67 million" in msg
+    p.deg_mode = _capi.DEG_LINEAR  # no stack: any length goes
     rc, msg = _create_status(p, g.tables, g.time_feat)
     assert rc != _capi.ERR_INVALID
     cfg = dict(g.cfg)
     cfg["episode_length"] = 24 * 90
-    with pytest.raises(ValueError, match="8188"):
-        validate_supported(resolve_config(cfg))
+    validate_supported(resolve_config(cfg))
 
 
 def test_create_range_checks_the_irregular_grid_tables():
