@@ -305,6 +305,30 @@ void build_seg_rows(const FleetParams& p, const FleetTables& t, std::vector<SegR
   }
 }
 
+// The auxiliary observation slots of every (row, EV), pre-assembled for the configured target SOC (observer_bl_pv.py:85-91
+// and, when normalising, oracle_normalization.py:127-131): float64 in the reference's operation order, stored as the
+// float32 words the reference would emit (`there` itself comes from the schedule record).
+void build_aux_rows(const FleetParams& p, const FleetTables& t, std::vector<AuxRec>& aux) {
+  const size_t TN = (size_t)p.table_rows * p.num_cars;
+  aux.assign(TN, AuxRec{0.0f, 0.0f, 0.0f, 0.0f});
+  if (!p.aux) return;
+  const bool norm = p.normalize != 0;
+  const double hn_den = p.evse_power * p.charging_eff;
+  for (size_t k = 0; k < TN; ++k) {
+    const double th = (double)t.there[k];
+    const double tgt_th = p.target_soc * th;
+    const double cl = tgt_th - t.soc_on_return[k];
+    const double hn = cl * p.batt_cap_nominal / hn_den;
+    double lax = ((double)t.time_left[k] / (hn + 0.001) - 1) * th;
+    lax = lax < 0 ? 0 : (lax > 5 ? 5 : lax);
+    AuxRec& x = aux[k];
+    x.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
+    x.cl = (float)(norm ? cl / p.max_soc : cl);
+    x.hn = (float)(norm ? hn / p.max_hours_needed : hn);
+    x.lax = (float)(norm ? lax / p.max_laxity : lax);
+  }
+}
+
 int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -372,6 +396,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     std::vector<SegRec> seg;
     build_seg_rows(*p, *t, seg);
     if ((rc = dev_upload(b, &d.seg, seg.data(), seg.size()))) return rc;
+    std::vector<AuxRec> aux;
+    build_aux_rows(*p, *t, aux);
+    if ((rc = dev_upload(b, &d.aux_tab, aux.data(), aux.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;

@@ -64,6 +64,17 @@ __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
   return left > 0 ? (float)((double)left * dt) : 0.0f;
 }
 
+// Pre-assembled auxiliary observation slots of (time row t, EV c) for the un-degraded target SOC, 16 B
+// (observer_bl_pv.py:85-91 + oracle_normalization.py:127-131), already normalised when normalize_in_env: the float32 words
+// the reference would emit.  Read by the step for the row it advanced to, off its critical path (only the observation
+// stores consume it); an EV whose target was raised to 0.9 (quirk Q7) computes its slots instead.
+struct AuxRec {
+  float tgt_th;  // target_soc * there
+  float cl;      // charging_left
+  float hn;      // hours_needed
+  float lax;     // laxity
+};
+
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
@@ -98,15 +109,28 @@ struct Hot {
 // episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
 #define HOT_SOC(h) ((HOT_FROZEN((h).bits) && !HOT_INPLANE((h).bits)) ? 0.0 : (h).x)
 
-// Env record, 64 B = one cache line: the 16-byte head every lane of the group needs (wave-uniform for G == 64),
-// followed by the episode statistics only the group's leader lane touches.  One pointer, one line per env and step
-// (separate planes cost a pointer pair and a cache line each).
+// What the step arithmetic needs of a physics row: the first 64 bytes of PhysRow.
+struct PhysHot {
+  double k_cost, k_rev, k_charge, k_discharge, load, pv, pv_share;
+  uint32_t flags_next, pad;
+};
+static_assert(sizeof(PhysHot) == 64 && sizeof(PhysRow) == 72, "PhysHot is the head of PhysRow");
+
+// Env record, 64 B: the 16-byte head every lane of the group needs (wave-uniform for G == 64), followed by the episode
+// statistics only the group's leader lane touches.  One pointer, one line per env and step.
+// The head also carries the FLEET_TFLAG_* bits of the row AFTER the current one (`flags_next` of the current row's physics
+// record), left there by the launch that advanced to the current row: the state machine needs them (lunch target, daily
+// degradation row) before the money terms need the physics record itself, and with them in the head nothing the step
+// needs early depends on the time row -- the physics record is requested when the head arrives and consumed last.
 struct EnvHead {
   int32_t t;         // current table row (episode.time)
   int32_t t_end;     // finish row (episode.finish_time)
-  int32_t nsamp;     // len(LogDataDeg.soc_log)
+  int32_t nsamp;     // [29:0] len(LogDataDeg.soc_log), [31:30] FLEET_TFLAG_* of row t + 1
   int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
 };
+#define HEAD_NSAMP(x) ((int32_t)((uint32_t)(x) & 0x3FFFFFFFu))
+#define HEAD_FLAGS(x) ((uint32_t)(x) >> 30)
+#define HEAD_PACK(nsamp, flags) ((int32_t)(((uint32_t)(nsamp) & 0x3FFFFFFFu) | ((uint32_t)(flags) << 30)))
 struct EnvRec {
   EnvHead h;
   int32_t ep_len;          // steps taken in the running episode
@@ -118,6 +142,7 @@ struct EnvRec {
   double cashflow;         // episode.current_charging_expense (last step)
   double penalty_record;   // episode.penalty_record
 };
+static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
 // Top of the rainflow reversal stack of (env e, EV c), 16 B: loaded with the hot record in rainflow mode so that
 // pushing a reversal point needs no dependent memory round trip.
@@ -179,6 +204,7 @@ struct FleetDev {
   double batt_cap_nominal, hn_denominator;  // auxiliary observation slots (observer_*.py:88): nominal capacity, evse * eta_c
   // ---- read-only tables ---------------------------------------------------------------------------------
   const SegRec* seg;          // [T,N] schedule records in run-length form
+  const AuxRec* aux_tab;      // [T,N] pre-assembled auxiliary observation slots (zeros when aux is off)
   const PhysRow* tab_phys;    // [T]
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]

@@ -179,24 +179,32 @@ __device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
 }
 
 // Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the step
-// advanced to (quirk Q10), in the reference's own float64 operations (observer_bl_pv.py:85-91, oracle_normalization.py:
-// 127-131) for the EV's target SOC (raised to 0.9 by quirk Q7 or not).
+// advanced to (quirk Q10): pre-assembled on the host for the configured target SOC (`ar`, requested by the caller as soon as
+// the row is known and consumed only here), computed in the reference's own float64 operations (observer_bl_pv.py:85-91,
+// oracle_normalization.py:127-131) for an EV whose target has been raised to 0.9 (quirk Q7).
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
-                                             const RowRec& tb) {
+                                             const RowRec& tb, const AuxRec& ar) {
   const int N = d.N;
   st_obs(row + c, (float)soc);
   st_obs(row + N + c, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
   st_obs(a + c, (float)tb.there);
+  if (!t090) {
+    st_obs(a + N + c, ar.tgt_th);
+    st_obs(a + 2 * N + c, ar.cl);
+    st_obs(a + 3 * N + c, ar.hn);
+    st_obs(a + 4 * N + c, ar.lax);
+    return;
+  }
+  const FleetCold* cd = d.self->cold;
   const double th = (double)tb.there;
-  const double tgt_th = (t090 ? 0.9 : d.target_soc) * th;
+  const double tgt_th = 0.9 * th;
   const double cl = tgt_th - tb.sor;
-  const double hn = cl * d.batt_cap_nominal / d.hn_denominator;
+  const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
   double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
   lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-  if (d.normalize) {
-    const FleetCold* cd = d.cold;
+  if (cd->normalize) {
     st_obs(a + N + c, (float)(tgt_th / cd->max_soc));
     st_obs(a + 2 * N + c, (float)(cl / cd->max_soc));
     st_obs(a + 3 * N + c, (float)(hn / cd->max_hours_needed));
@@ -301,18 +309,58 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
 // size; when the three-point rule drops the FIRST point -- the stack is exactly [a, b, p] then -- the two survivors are
 // rewritten to slots 0 and 1, so no head index exists and the size alone describes it); its top two entries travel in
 // registers (`top`, from the RfTop record).
-__device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, int& tail, RfTop& top, uint32_t& err) {
+// The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
+// state machine, knows the new sample, therefore whether a reversal point is pushed and -- from the cached top -- whether
+// that closes a cycle, and REQUESTS what a closure needs of the row (accumulators + the four entries below the top two);
+// `rf_finish`, after the observation stores, the money terms (and, one EV per lane, the per-env reductions), consumes it.
+struct RfReq {
+  double p;               // the reversal point to push
+  RfAcc acc;              // requested when the push closes a cycle
+  double w0, w1, w2, w3;  // stack[tail-3], [tail-4], [tail-5], [tail-6] (before the push)
+  bool push, closes;
+};
+__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, const RfTop& top,
+                                         RfReq& q) {
+  q.push = false;
+  q.closes = false;
+  q.p = old_deg;
+  // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes the previous
+  // sample a reversal point
+  if (soc_deg != old_deg) {
+    const int s_next = (soc_deg > old_deg) ? 1 : 2;
+    q.push = (sgn != 0 && sgn != s_next);
+    sgn = s_next;
+  }
+  if (q.push) {
+    q.closes = (tail + 1 >= 3) && !(fabs(old_deg - top.s2) < fabs(top.s2 - top.s1));
+    if (q.closes) {
+      const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+      q.acc = *reinterpret_cast<const RfAcc*>(row);
+      // stack[tail-6 .. tail-3]; for a shallow stack the low words fall into the row's own header (never used: `nwin`)
+      const double* w = row + 4 + (tail - 6);  // tail >= 2 here
+      q.w3 = w[0];
+      q.w2 = w[1];
+      q.w1 = w[2];
+      q.w0 = w[3];
+    }
+  }
+}
+__device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfReq& q, int& tail, RfTop& top, uint32_t& err) {
+  if (!q.push) return;
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
   double* stk = row + 4;  // the stack follows the RfAcc header in the same 128-byte-aligned row
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
+  const double p = q.p;
   double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
+  int nwin = tail - 2 > 4 ? 4 : tail - 2;  // entries below them that are in registers
+  double w0 = q.w0, w1 = q.w1, w2 = q.w2, w3 = q.w3;
   stk[tail] = p;
   tail += 1;  // >= 2: the episode's first sample is always on the stack
-  if (tail >= 3 && !(fabs(p - b) < fabs(b - a))) {
-    RfAcc acc = *reinterpret_cast<RfAcc*>(row);
+  if (q.closes) {
+    RfAcc acc = q.acc;
     const int L = acc.rf_len;
     int nc = acc.nc;
     double mean_sum = acc.mean_sum, csum = acc.csum;
@@ -329,8 +377,17 @@ __device__ __forceinline__ void rf_push(const FleetDev& d, size_t i, double p, i
       } else {  // full cycle, drop its two points -> stack = [..., p]
         tail -= 2;
         stk[tail - 1] = p;
-        b = stk[tail - 2];                       // tail >= 2 here
-        a = (tail >= 3) ? stk[tail - 3] : 0.0;
+        if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
+        else b = stk[tail - 2];
+        if (tail >= 3) {
+          if (nwin >= 2) a = w1;                     // stack[tail-3]
+          else a = stk[tail - 3];
+        } else {
+          a = 0.0;
+        }
+        w0 = w2;
+        w1 = w3;
+        nwin = nwin > 2 ? nwin - 2 : 0;
       }
     }
     acc.nc = nc;
@@ -520,9 +577,10 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       *reinterpret_cast<RfAcc*>(row) = acc;
       row[4] = soc_deg;
     }
-    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb);
+    const AuxRec ar = d.aux_tab[(size_t)start * N + c];
+    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
     if (log_on) {
-      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb);
+      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb, ar);
       double* lev = d.log_ev + lrow * 4 * N + c;
       lev[0] = 0.0;
       lev[N] = 0.0;
@@ -542,7 +600,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   }
   if (leader) {
     EnvRec* er = d.env + e;
-    er->h = r;
+    EnvHead hd = r;
+    hd.nsamp = HEAD_PACK(r.nsamp, d.tab_phys[start].flags_next);  // the row flags the episode's first step needs
+    er->h = hd;
     er->ep_return = 0.0;
     er->ep_len = 0;
     er->penalty_record = 0.0;
@@ -558,6 +618,7 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   if (e >= d.E) return;
   if (mask && !mask[e]) return;
   EnvHead r = d.env[e].h;
+  r.nsamp = HEAD_NSAMP(r.nsamp);
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
   if (d.env[e].ep_len > 0 && d.env[e].start_done >= 0) r.episodes += 1;
   int lp = d.log_pos ? d.log_pos[e] : 0;
@@ -573,13 +634,14 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false>
+template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
 __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
-    // fleetrl_amd/build.py): what the first loads of a wavefront need -- its env record, its lanes' state records and action
-    // -- is passed here once more, ahead of the argument block, so that those loads do not wait for an argument fetch.
-    EnvRec* __restrict__ p_env, const Hot* __restrict__ p_hot, const double* __restrict__ p_soh, const RfTop* __restrict__ p_rf_top,
-    const void* __restrict__ p_actions, int p_E, int p_N,
+    // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
+    // its lanes' state records and action, E and N for their addresses -- is passed here once more, ahead of the argument
+    // block, so that those loads do not wait for an argument fetch.
+    const Hot* __restrict__ p_hot, const SegRec* __restrict__ p_run, const double* __restrict__ p_soh,
+    const RfTop* __restrict__ p_rf_top, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* __restrict__ p_env,
     FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
@@ -607,14 +669,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   RfTop top_pre = {0.0, 0.0};
   float a32_pre = 0.0f;
   double a64_pre = 0.0;
-  if (kEarly && g < N) {
-    const size_t i0 = (size_t)e * N + g;
+  if (kEarly) {
+    // unconditional, straight-line requests (surplus lanes of the group re-read the env's last EV and drop it): no
+    // exec-mask region for the compiler to close with a wait before the env record is even requested
+    const size_t i0 = (size_t)e * N + (g < N ? g : N - 1);
+    // in the order the step consumes them (the memory system serves the chip-wide burst of these requests roughly first
+    // come, first served, and a wavefront's wait counts its loads in issue order): what the charge arithmetic needs first
     h_pre = p_hot[i0];
-    run_pre = d.run[i0];
     soh_pre = p_soh[i0];
-    if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
-    if (act_mode == FLEET_ACT_F64) a64_pre = ((const double*)p_actions)[i0];
+    if (A64) a64_pre = ((const double*)p_actions)[i0];
     else a32_pre = ((const float*)p_actions)[i0];
+    run_pre = p_run[i0];
+    if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
   }
 
   EnvHead r = p_env[e].h;
@@ -624,6 +690,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     r.nsamp = __builtin_amdgcn_readfirstlane(r.nsamp);
     r.episodes = __builtin_amdgcn_readfirstlane(r.episodes);
   }
+  const uint32_t head_flags = HEAD_FLAGS(r.nsamp);  // FLEET_TFLAG_* of row t + 1, left by the previous launch
+  r.nsamp = HEAD_NSAMP(r.nsamp);
   double ep_return = 0.0, penalty_record = 0.0;
   int ep_len = 0;
   if (leader) {
@@ -659,6 +727,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   const bool rt = MULTI && (d.real_time != 0);
   double last_rew = 0.0;
   bool last_done = false;
+  uint32_t head_after = 0;   // single step: FLEET_TFLAG_* of the row after the one the launch advances to
+  bool head_reset = false;   // the env was reset in this launch: its head describes the new start row
   for (int k = 0; rt || k < steps; ++k) {
     const int t = r.t;
     int t1 = t + 1;  // :508
@@ -676,10 +746,16 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // The 72-byte row is wave-uniform for G == 64, but keeping it in scalar registers for the whole lane loop costs 16
     // of the ~100 SGPRs (spills); a deliberately lane-indexed (vzero == 0) load puts it in vector registers instead.
     // (not in rainflow mode, where vector registers are the scarcer resource)
-    const PhysRow ph = d.tab_phys[t + (DEG == FLEET_DEG_RAINFLOW ? 0 : vzero)];
+    // One step per launch: requested as a lane-indexed (vector) load when the head arrives and consumed last -- by the money
+    // terms, after the state machine and the observation stores -- so that no wait on the scalar side stands between the
+    // arrival of the state records and the charge arithmetic; the row flags the state machine needs come with the head.
+    const PhysHot ph = *reinterpret_cast<const PhysHot*>(d.tab_phys + (t + ((kEarly || DEG != FLEET_DEG_RAINFLOW) ? vzero : 0)));
+    // flags of the row after t1, for the head the next launch reads
+    uint32_t flags_after = 0;
+    if (kEarly) flags_after = reinterpret_cast<const PhysHot*>(d.tab_phys + (t1 + vzero))->flags_next;
     // hours this step spans: `get_next_dt` (:455, :994-1008) -- a constant unless the grid is irregular (real_time only)
-    const double dt_step = rt ? ph.dt : d.dt;
-    const uint32_t flags1 = ph.flags_next;
+    const double dt_step = rt ? d.tab_phys[t].dt : d.dt;
+    const uint32_t flags1 = kEarly ? head_flags : ph.flags_next;
     const bool lunch = d.is_caretaker && (flags1 & FLEET_TFLAG_LUNCH);
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     // the few wavefronts with extra work after the step (daily evaluation, episode end + reset) finish last and set the
@@ -739,12 +815,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       const double soh0 = kEarly ? soh_pre : d.soh[i];
       RfTop top = {0.0, 0.0};
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
-      // the schedule record of the row AFTER next, for the next launch: only when that row starts a new segment of the EV's
-      // schedule (a departure, an arrival, ...).  Nothing in this step waits for it except the store at its very end.
-      const bool crosses = (t1 + 1 >= SEG_END(rr.se));
-      SegRec nr = rr;
-      if (crosses) nr = d.seg[(size_t)t2 * N + c];
-      const RowRec tb1 = seg_row(rr, t1, d.dt);
+      // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
+      AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (write_step_obs || logs) ar = d.aux_tab[(size_t)t1 * N + c];
       // last logged SOC sample: shares the record's float64 field with the SOC (struct Hot); the soc_deg plane only holds
       // it in a combination that does not occur inside the reference's episodes (dependent load, INPLANE)
       const bool inplane = HOT_INPLANE(hb.bits);
@@ -772,10 +845,16 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         // the widening must stay here: hoisted into the early-load block it would wait for every outstanding load
         float a32 = a32_pre;
         asm volatile("" : "+v"(a32));
-        a = (act_mode == FLEET_ACT_F64) ? a64_pre : (double)a32;
+        a = A64 ? a64_pre : (double)a32;
       } else {
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
+      // the schedule record of the row AFTER next, for the next launch: only when that row starts a new segment of the EV's
+      // schedule (a departure, an arrival, ...).  Nothing in this step waits for it except the store at its very end.
+      const bool crosses = (t1 + 1 >= SEG_END(rr.se));
+      SegRec nr = rr;
+      if (crosses) nr = d.seg[(size_t)t2 * N + c];
+      const RowRec tb1 = seg_row(rr, t1, d.dt);
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
       double soc = HOT_SOC(hb);
       float hl = hb.hl;
@@ -806,9 +885,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
       if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
       soc = soc + (pos ? en * d.eta_c : en) / cap;  // :128 / :189
-      const double grid_e = fmax(en - ph.pv_share, 0.0);  // :142 (charging only)
-      cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
-      rew += pos ? ph.k_charge * grid_e : ph.k_discharge * en;   // :154-156 / :204-206
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
@@ -834,29 +910,33 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
       if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
+      // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
+      // here and consumed after the observation stores and the money terms
+      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+      RfReq rq;
+      rq.push = false;
+      if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, top, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
-      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1);
-      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1);
+      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
+      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1, ar);
+
+      // ---- money terms of EvCharger.charge: the only consumers of the time row's physics record, which was requested when
+      // the env head arrived and has had the charge arithmetic, the state machine and the observation stores to get here
+      {
+        const double grid_e = fmax(en - ph.pv_share, 0.0);  // :142 (charging only)
+        cash += pos ? -(grid_e * ph.k_cost) : en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
+        rew += pos ? ph.k_charge * grid_e : ph.k_discharge * en;   // :154-156 / :204-206
+      }
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
-      bool pushed = false;
       double soh = soh0;
       if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
-        // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes
-        // the previous sample a reversal point
-        if (soc_deg != old_deg) {
-          const int s_next = (soc_deg > old_deg) ? 1 : 2;
-          if (sgn != 0 && sgn != s_next) {
-            rf_push(d, i, old_deg, tail, top, err);
-            pushed = true;
-          }
-          sgn = s_next;
-        }
+        rf_finish(d, i, rq, tail, top, err);
       }
+      const bool pushed = rq.push;
       if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
       if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
         sei_sample = soc_deg;
@@ -956,6 +1036,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
     }
     if (logs) lp += 1;
+    head_after = flags_after;
     if (is_done) {
       n_done += 1;
       if (leader && env_ok) {
@@ -966,6 +1047,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
       r.episodes += 1;
       if (resets) {
+        head_reset = true;
         if (env_ok) {
           reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
         } else {  // surplus group: keep its registers moving without touching memory
@@ -990,6 +1072,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
   if (leader && env_ok) {
     EnvRec* er = d.env + e;
+    // the head carries the row flags the next launch's state machine needs (struct EnvHead)
+    uint32_t nflags = head_after;
+    if (!kEarly || head_reset) nflags = d.tab_phys[r.t].flags_next;
+    r.nsamp = HEAD_PACK(r.nsamp, nflags);
     er->h = r;
     er->ep_return = ep_return;
     er->ep_len = ep_len;
@@ -1114,7 +1200,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-#define FLEET_PRE_ARGS d.env, d.hot, d.soh, d.rf_top, actions, d.E, d.N,  /* the preloaded leading arguments */
+#define FLEET_PRE_ARGS d.hot, d.run, d.soh, d.rf_top, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
@@ -1128,7 +1214,10 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
   } else {
-    if (single)
+    if (single && f64 == FLEET_ACT_F64)
+      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
+                         reward, done, terminal_obs, done_count);
+    else if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
                          terminal_obs, done_count);
     else if (d.log_pos)
