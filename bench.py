@@ -301,8 +301,10 @@ def main():
     r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
     barrier()
     gather_ms = (time.perf_counter() - t1) * 1e3
+    check = os.environ.get("FLEET_BENCH_NO_ERRCHECK") != "1"  # diagnostics only (tools/ab_noerr.sh: ablation builds)
     for g in groups:
-        g.batch.check_errors()
+        if check:
+            g.batch.check_errors()
 
     out = None
     if rank == 0:
@@ -325,7 +327,8 @@ def main():
         for _ in range(reps):
             g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
         many_ms = g0.batch.timer_stop()
-        g0.batch.check_errors()
+        if check:
+            g0.batch.check_errors()
         fleets = "+".join(g.use_case for g in groups)
         graph_used = use_graph and args.steps >= L
         out = {

@@ -450,7 +450,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     if ((rc = dev_alloc(b, &d.rf_top, EN))) return rc;
     // RfAcc headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
     RfAcc acc0;
-    acc0.mean_sum = 0; acc0.csum = 0; acc0.nc = 0; acc0.rf_len = 1; acc0.pad = 0;
+    acc0.mean_sum = 0; acc0.csum = 0; acc0.nc = 0; acc0.rf_len = 1; acc0.pad = 0;  // field order: see struct RfAcc
     std::vector<RfAcc> accs(EN, acc0);
     HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, accs.data(), sizeof(RfAcc), sizeof(RfAcc), EN,
                                 hipMemcpyHostToDevice, b->stream));

@@ -144,22 +144,31 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Top of the rainflow reversal stack of (env e, EV c), 16 B: loaded with the hot record in rainflow mode so that
-// pushing a reversal point needs no dependent memory round trip.
+// Top of the rainflow reversal stack of (env e, EV c), 16 B, loaded with the hot record in rainflow mode: whether a step
+// pushes a reversal point, and whether that push closes a cycle, is decided from it without touching the EV's row.
+// `s2` is the ONLY copy of the newest entry: the row holds the entries below it (stack[0 .. tail-2]; `s1` caches the last
+// of them).  A push that closes no cycle therefore writes one word to the row (the displaced old top), and a push that
+// closes a full cycle writes none (the two popped points vanish, the new point stays here).
 struct RfTop {
   double s1;  // stack[tail-2]
   double s2;  // stack[tail-1]
 };
 
-// Rainflow accumulators of (env e, EV c), 32 B, touched only when a cycle closes and on the daily row: one record =
-// one cache line per event (separate planes cost one line per field).
+// Rainflow accumulators of (env e, EV c), the 32-byte header of the EV's rainflow row, touched only when a cycle closes
+// and on the daily row.  What every closure reads and writes sits in its first 16 bytes (one load, one store per lane).
 struct RfAcc {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
-  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1
   int32_t nc;       // closed cycles this episode
   int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_finish)
   double pad;
 };
+struct RfAccHead {  // first half of RfAcc
+  double mean_sum;
+  int32_t nc;
+  int32_t rf_len;
+};
+static_assert(sizeof(RfAcc) == 32 && sizeof(RfAccHead) == 16, "RfAccHead is the head of RfAcc");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc

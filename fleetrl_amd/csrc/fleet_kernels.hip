@@ -157,12 +157,50 @@ __device__ __forceinline__ double overloading_penalty(double rel, double scale) 
 // ---------------------------------------------------------------------------------------------------------
 // observation assembly (observer_*.py + normalization/*.py); layout: DESIGN.md "Observation row"
 // ---------------------------------------------------------------------------------------------------------
+// Store policies (experiments, tools/ab_build.sh): 0 = plain (write-back L2), 1 = nt, 2 = sc1 (write-through)
+#ifndef FLEET_ST_HOT
+#define FLEET_ST_HOT 0
+#endif
+#ifndef FLEET_ST_RF
+#define FLEET_ST_RF 0
+#endif
+#ifndef FLEET_ST_OBS
+#define FLEET_ST_OBS 0
+#endif
+typedef float fleet_v4f __attribute__((ext_vector_type(4)));
+typedef float fleet_v2f __attribute__((ext_vector_type(2)));
+template <int MODE, typename T>
+__device__ __forceinline__ void st_pol(T* p, const T& v) {
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8 || sizeof(T) == 4, "4-, 8- or 16-byte store");
+  if (MODE == 0) {
+    *p = v;
+  } else if (sizeof(T) == 16) {
+    fleet_v4f w;
+    __builtin_memcpy(&w, &v, 16);
+    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<fleet_v4f*>(p));
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+  } else if (sizeof(T) == 8) {
+    fleet_v2f w;
+    __builtin_memcpy(&w, &v, 8);
+    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<fleet_v2f*>(p));
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+  } else {
+    float w;
+    __builtin_memcpy(&w, &v, 4);
+    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<float*>(p));
+    else asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+  }
+}
 template <typename T>
 __device__ __forceinline__ void st_rec16(T* p, const T& v) {
   static_assert(sizeof(T) == 16, "16-byte record");
-  *p = v;
+  st_pol<FLEET_ST_HOT>(p, v);
 }
-__device__ __forceinline__ void st_obs(float* p, float v) { *p = v; }
+#ifdef FLEET_ABL_NO_OBS  // diagnostic builds (tools/ab_build.sh): wrong results on purpose
+__device__ __forceinline__ void st_obs(float*, float) {}
+#else
+__device__ __forceinline__ void st_obs(float* p, float v) { st_pol<FLEET_ST_OBS>(p, v); }
+#endif
 
 // The three schedule columns of one (row, EV), decoded from the record of the row's segment.
 struct RowRec {
@@ -305,18 +343,20 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
 
 // A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
 // three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
-// The stack of the EV lives in its rainflow row behind the RfAcc header and always starts at slot 0 (`tail` = its
-// size; when the three-point rule drops the FIRST point -- the stack is exactly [a, b, p] then -- the two survivors are
-// rewritten to slots 0 and 1, so no head index exists and the size alone describes it); its top two entries travel in
-// registers (`top`, from the RfTop record).
+// The stack of the EV always starts at slot 0 (`tail` = its size; when the three-point rule drops the FIRST point -- the
+// stack is exactly [a, b, p] then -- the survivor below the top is rewritten to slot 0, so no head index exists and the size
+// alone describes it).  Its newest entry lives in the RfTop record only, the entries below it in the EV's rainflow row
+// behind the RfAcc header (struct RfTop in fleet_device.h); RfTop also caches the second newest.
 // The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
 // state machine, knows the new sample, therefore whether a reversal point is pushed and -- from the cached top -- whether
-// that closes a cycle, and REQUESTS what a closure needs of the row (accumulators + the four entries below the top two);
-// `rf_finish`, after the observation stores, the money terms (and, one EV per lane, the per-env reductions), consumes it.
+// that closes a cycle, and REQUESTS what a closure needs of the row (the head of the accumulators and the two entries
+// below the cached ones: one 16-byte load each); `rf_finish`, after the observation stores and the money terms, consumes
+// it.  Sparse accesses are what a push costs (every lane its own cache line): a push that closes nothing is ONE 8-byte
+// store, a push that closes one full cycle two loads and one store, none of them to the stack.
 struct RfReq {
-  double p;               // the reversal point to push
-  RfAcc acc;              // requested when the push closes a cycle
-  double w0, w1, w2, w3;  // stack[tail-3], [tail-4], [tail-5], [tail-6] (before the push)
+  double p;        // the reversal point to push
+  RfAccHead acc;   // requested when the push closes a cycle
+  double w0, w1;   // stack[tail-3], [tail-4] (before the push)
   bool push, closes;
 };
 __device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, const RfTop& top,
@@ -328,20 +368,29 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old
   // sample a reversal point
   if (soc_deg != old_deg) {
     const int s_next = (soc_deg > old_deg) ? 1 : 2;
+#ifdef FLEET_ABL_NO_PUSH
+    q.push = false;
+#else
     q.push = (sgn != 0 && sgn != s_next);
+#endif
     sgn = s_next;
   }
   if (q.push) {
     q.closes = (tail + 1 >= 3) && !(fabs(old_deg - top.s2) < fabs(top.s2 - top.s1));
+#ifdef FLEET_ABL_NO_CLOSE
+    q.closes = false;
+#endif
     if (q.closes) {
       const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-      q.acc = *reinterpret_cast<const RfAcc*>(row);
-      // stack[tail-6 .. tail-3]; for a shallow stack the low words fall into the row's own header (never used: `nwin`)
-      const double* w = row + 4 + (tail - 6);  // tail >= 2 here
-      q.w3 = w[0];
-      q.w2 = w[1];
-      q.w1 = w[2];
-      q.w0 = w[3];
+#ifdef FLEET_ABL_NO_RFLOADS
+      q.acc.mean_sum = 0.0; q.acc.nc = 0; q.acc.rf_len = 1000000; q.w1 = 0.25; q.w0 = 0.75;
+#else
+      q.acc = *reinterpret_cast<const RfAccHead*>(row);
+      // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
+      const double* w = row + 4 + (tail - 4);  // tail >= 2 here
+      q.w1 = w[0];
+      q.w0 = w[1];
+#endif
     }
   }
 }
@@ -354,47 +403,60 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
     return;
   }
   const double p = q.p;
-  double a = top.s1, b = top.s2;  // stack[tail-2], stack[tail-1]
-  int nwin = tail - 2 > 4 ? 4 : tail - 2;  // entries below them that are in registers
-  double w0 = q.w0, w1 = q.w1, w2 = q.w2, w3 = q.w3;
-  stk[tail] = p;
-  tail += 1;  // >= 2: the episode's first sample is always on the stack
-  if (q.closes) {
-    RfAcc acc = q.acc;
-    const int L = acc.rf_len;
-    int nc = acc.nc;
-    double mean_sum = acc.mean_sum, csum = acc.csum;
-    while (tail >= 3) {
-      const double X = fabs(p - b), Y = fabs(b - a);
-      if (X < Y) break;
-      if (nc >= L - 1) csum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
-      mean_sum += 0.5 * (a + b);
-      nc += 1;
-      if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
-        stk[0] = b;
-        stk[1] = p;
-        tail = 2;
-      } else {  // full cycle, drop its two points -> stack = [..., p]
-        tail -= 2;
-        stk[tail - 1] = p;
-        if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
-        else b = stk[tail - 2];
-        if (tail >= 3) {
-          if (nwin >= 2) a = w1;                     // stack[tail-3]
-          else a = stk[tail - 3];
-        } else {
-          a = 0.0;
-        }
-        w0 = w2;
-        w1 = w3;
-        nwin = nwin > 2 ? nwin - 2 : 0;
-      }
-    }
-    acc.nc = nc;
-    acc.mean_sum = mean_sum;
-    acc.csum = csum;
-    *reinterpret_cast<RfAcc*>(row) = acc;
+  double a = top.s1, b = top.s2;  // stack[tail-2] (also in the row), stack[tail-1] (only here)
+  if (!q.closes) {
+#ifndef FLEET_ABL_NO_STKSTORE
+    st_pol<FLEET_ST_RF>(stk + (tail - 1), b);  // the displaced top joins the row; tail >= 1: the episode's first sample is always on the stack
+#endif
+#ifdef FLEET_ABL_NO_CLOSE
+    tail = tail < 6 ? tail + 1 : 3;
+#else
+    tail += 1;
+#endif
+    top.s1 = b;
+    top.s2 = p;
+    return;
   }
+  int nwin = tail - 2 > 2 ? 2 : tail - 2;  // entries below the cached ones that are in registers
+  const double w0 = q.w0, w1 = q.w1;
+  tail += 1;
+  const int L = q.acc.rf_len;
+  int nc = q.acc.nc;
+  double mean_sum = q.acc.mean_sum, dcsum = 0.0;
+  bool has_csum = false;
+  while (tail >= 3) {
+    const double X = fabs(p - b), Y = fabs(b - a);
+    if (X < Y) break;
+    if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
+      dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
+      has_csum = true;
+    }
+    mean_sum += 0.5 * (a + b);
+    nc += 1;
+    if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
+      stk[0] = b;
+      tail = 2;
+    } else {  // full cycle, drop its two points -> stack = [..., p]: the row keeps what it has, p lives in the top record
+      tail -= 2;
+      if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
+      else b = stk[tail - 2];
+      if (tail >= 3) {
+        if (nwin >= 2) a = w1;                     // stack[tail-3]
+        else a = stk[tail - 3];
+      } else {
+        a = 0.0;
+      }
+      nwin = 0;
+    }
+  }
+  RfAccHead out;
+  out.mean_sum = mean_sum;
+  out.nc = nc;
+  out.rf_len = L;
+#ifndef FLEET_ABL_NO_ACCSTORE
+  st_pol<FLEET_ST_RF>(reinterpret_cast<RfAccHead*>(row), out);
+#endif
+  if (has_csum) reinterpret_cast<RfAcc*>(row)->csum += dcsum;
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
 }
@@ -574,8 +636,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       acc.mean_sum = 0.0;
       acc.csum = 0.0;
       acc.nc = 0;
-      *reinterpret_cast<RfAcc*>(row) = acc;
-      row[4] = soc_deg;
+      *reinterpret_cast<RfAcc*>(row) = acc;  // the stack is [soc_deg]: its only entry lives in the top record
     }
     const AuxRec ar = d.aux_tab[(size_t)start * N + c];
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
@@ -624,6 +685,50 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   int lp = d.log_pos ? d.log_pos[e] : 0;
   reset_env<G, true>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
+}
+
+// The tail of an EV's step: the rainflow push (second half), the linear model's daily update, the data-log row, and the
+// stores of the state records that changed.
+template <int DEG, bool WIDE>
+__device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
+                                          int tail, int sgn, RfTop top, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
+                                          bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
+                                          size_t lrow, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail, RfTop& sei_top) {
+  double soh = soh0;
+  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, err);
+  const bool pushed = rq.push;
+  if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
+  if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
+    sei_sample = soc_deg;
+    sei_soh = soh0;
+    sei_tail = tail;
+    sei_top = top;
+  }
+  if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
+    double* lev = d.log_ev + lrow * 4 * N + c;
+    lev[0] = a;
+    lev[N] = en;
+    lev[2 * N] = soh0 - soh;
+    lev[3 * N] = soh;
+  }
+  FLEET_STAMP(5);
+  if (env_ok) {
+    // the whole 16-byte record, always: dense full-line stores.  soc_deg == soc whenever the EV has hours left;
+    // otherwise it keeps its previous value, which shares the record's float64 field with an empty slot's soc == 0
+#ifndef FLEET_ABL_NO_HOTSTORE
+    st_rec16(d.hot + i, hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane));
+#endif
+    if (crosses) st_rec16(d.run + i, nr);  // the next launch advances into another segment of the EV's schedule
+    if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
+    // the cached stack top only changes when a reversal point was pushed
+#ifndef FLEET_ABL_NO_TOPSTORE
+#ifdef FLEET_TOP_ALWAYS  // experiment: whole lines instead of the pushing lanes' 16-byte pieces
+    if (DEG == FLEET_DEG_RAINFLOW) st_pol<FLEET_ST_RF>(d.rf_top + i, top);
+#else
+    if (DEG == FLEET_DEG_RAINFLOW && pushed) st_pol<FLEET_ST_RF>(d.rf_top + i, top);
+#endif
+#endif
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -680,7 +785,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     if (A64) a64_pre = ((const double*)p_actions)[i0];
     else a32_pre = ((const float*)p_actions)[i0];
     run_pre = p_run[i0];
+#ifndef FLEET_ABL_NO_TOPLOAD
     if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
+#endif
   }
 
   EnvHead r = p_env[e].h;
@@ -807,6 +914,24 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     int sei_tail = 0;
     RfTop sei_top = {0.0, 0.0};
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
+    // one EV per lane and one step per launch: the tail of the EV's step (rainflow push, state stores) is deferred until
+    // after the per-env reductions, so that the push's memory round trip has them to hide behind as well
+#ifdef FLEET_RF_LATE
+    constexpr bool kLate = kEarly && !LOG;
+#else
+    constexpr bool kLate = false;
+#endif
+    size_t lt_i = 0;
+    int lt_c = 0, lt_tail = 0, lt_sgn = 0;
+    RfReq lt_rq;
+    lt_rq.push = false;
+    lt_rq.closes = false;
+    RfTop lt_top = {0.0, 0.0};
+    double lt_soc = 0.0, lt_soc_deg = 0.0, lt_old_deg = 0.0, lt_soh0 = 0.0;
+    float lt_hl = 0.0f;
+    uint32_t lt_there = 0;
+    bool lt_t090 = false, lt_inplane = false, lt_crosses = false, lt_valid = false;
+    SegRec lt_nr = {0.0, 0u, 0u};
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
@@ -817,7 +942,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
       // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
       AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef FLEET_ABL_NO_AUXLOAD
       if (write_step_obs || logs) ar = d.aux_tab[(size_t)t1 * N + c];
+#endif
       // last logged SOC sample: shares the record's float64 field with the SOC (struct Hot); the soc_deg plane only holds
       // it in a combination that does not occur inside the reference's episodes (dependent load, INPLANE)
       const bool inplane = HOT_INPLANE(hb.bits);
@@ -894,7 +1021,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
         const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
+#ifdef FLEET_ABL_NO_DEPPEN
+        if (false) {
+#else
         if (missing > d.eps) {
+#endif
           const double pen = soc_violation_penalty(missing);
           rew += pen;
           penrec += pen;  // episode.penalty_record (:549,566,584)
@@ -932,36 +1063,28 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      double soh = soh0;
-      if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
-        rf_finish(d, i, rq, tail, top, err);
+      if (kLate) {  // one EV per lane: the rest of the EV's step runs after the per-env reductions (below)
+        lt_i = i;
+        lt_c = c;
+        lt_rq = rq;
+        lt_tail = tail;
+        lt_sgn = sgn;
+        lt_top = top;
+        lt_soc = soc;
+        lt_soc_deg = soc_deg;
+        lt_old_deg = old_deg;
+        lt_hl = hl;
+        lt_there = tb1.there;
+        lt_t090 = t090;
+        lt_inplane = inplane;
+        lt_crosses = crosses;
+        lt_nr = nr;
+        lt_soh0 = soh0;
+        lt_valid = true;
+        break;
       }
-      const bool pushed = rq.push;
-      if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
-      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
-        sei_sample = soc_deg;
-        sei_soh = soh0;
-        sei_tail = tail;
-        sei_top = top;
-      }
-      if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
-        double* lev = d.log_ev + lrow * 4 * N + c;
-        lev[0] = a;
-        lev[N] = en;
-        lev[2 * N] = soh0 - soh;
-        lev[3 * N] = soh;
-      }
-
-      FLEET_STAMP(5);
-      if (env_ok) {
-        // the whole 16-byte record, always: dense full-line stores.  soc_deg == soc whenever the EV has hours left;
-        // otherwise it keeps its previous value, which shares the record's float64 field with an empty slot's soc == 0
-        st_rec16(d.hot + i, hot_encode(d, i, soc, soc_deg, hl, tail, sgn, tb1.there, t090, inplane));
-        if (crosses) st_rec16(d.run + i, nr);  // the next launch advances into another segment of the EV's schedule
-        if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
-        // the cached stack top only changes when a reversal point was pushed
-        if (DEG == FLEET_DEG_RAINFLOW && pushed) st_rec16(d.rf_top + i, top);
-      }
+      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, top, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
+                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -970,9 +1093,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
+#ifndef FLEET_ABL_NO_REDUCE
     cash = group_sum_to_last<G>(cash);
     rew = group_sum_to_last<G>(rew);
     asum = group_sum_to_last<G>(asum);
+#endif
     if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
     if (log_on) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
@@ -1007,6 +1132,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         }
       }
     }
+    if (kLate && lt_valid)
+      ev_finish<DEG, WIDE>(d, lt_i, lt_c, N, env_ok, deg_row, dt_step, lt_rq, lt_tail, lt_sgn, lt_top, lt_soc, lt_soc_deg, lt_old_deg, lt_hl,
+                           lt_there, lt_t090, lt_inplane, lt_crosses, lt_nr, lt_soh0, 0.0, 0.0, false, 0, err, sei_sample, sei_soh, sei_tail,
+                           sei_top);
     FLEET_STAMP(7);
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
