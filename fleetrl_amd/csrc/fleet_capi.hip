@@ -445,14 +445,14 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   }
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
-    d.rf_row_stride = ((4 + d.stack_cap + 15) / 16) * 16;  // RfAcc header + stack, rounded to whole 128-byte lines
+    d.rf_row_stride = ((RF_HDR_WORDS + d.stack_cap + 15) / 16) * 16;  // RfHdr + stack, rounded to whole 128-byte lines
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
-    if ((rc = dev_alloc(b, &d.rf_top, EN))) return rc;
-    // RfAcc headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
-    RfAcc acc0;
-    acc0.mean_sum = 0; acc0.csum = 0; acc0.nc = 0; acc0.rf_len = 1; acc0.pad = 0;  // field order: see struct RfAcc
-    std::vector<RfAcc> accs(EN, acc0);
-    HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, accs.data(), sizeof(RfAcc), sizeof(RfAcc), EN,
+    // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
+    RfHdr h0;
+    memset(&h0, 0, sizeof h0);
+    h0.rf_len = 1;
+    std::vector<RfHdr> hdrs(EN, h0);
+    HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, hdrs.data(), sizeof(RfHdr), sizeof(RfHdr), EN,
                                 hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }

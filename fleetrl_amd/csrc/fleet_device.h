@@ -144,31 +144,34 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Top of the rainflow reversal stack of (env e, EV c), 16 B, loaded with the hot record in rainflow mode: whether a step
-// pushes a reversal point, and whether that push closes a cycle, is decided from it without touching the EV's row.
-// `s2` is the ONLY copy of the newest entry: the row holds the entries below it (stack[0 .. tail-2]; `s1` caches the last
-// of them).  A push that closes no cycle therefore writes one word to the row (the displaced old top), and a push that
-// closes a full cycle writes none (the two popped points vanish, the new point stays here).
-struct RfTop {
-  double s1;  // stack[tail-2]
-  double s2;  // stack[tail-1]
-};
-
-// Rainflow accumulators of (env e, EV c), the 32-byte header of the EV's rainflow row, touched only when a cycle closes
-// and on the daily row.  What every closure reads and writes sits in its first 16 bytes (one load, one store per lane).
-struct RfAcc {
+// Rainflow row of (env e, EV c): a 48-byte header followed by the reversal stack, 128-byte aligned, so that everything a
+// push touches -- accumulators, the two newest stack entries, the entries right below them -- sits in ONE cache line for
+// the usual stack depths.  Nothing of it is read by a step that pushes no reversal point (three steps in four): whether
+// a step pushes is decided from the hot record alone (sign of the last slope), and only then is the row requested.
+//   * `s2` is the ONLY copy of the newest stack entry: the stack words hold the entries below it (stack[0 .. tail-2];
+//     `s1` caches the last of them).  A push that closes no cycle therefore writes one stack word (the displaced old
+//     top), and a push that closes a full cycle writes none (the two popped points vanish, the new point stays in s2).
+//   * what every closure reads and writes sits in the first 16 bytes, the stack top in the next 16.
+struct RfHdr {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
   int32_t nc;       // closed cycles this episode
   int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
+  double s1;        // stack[tail-2]
+  double s2;        // stack[tail-1]
   double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_finish)
   double pad;
 };
-struct RfAccHead {  // first half of RfAcc
+struct RfAccHead {  // bytes 0..15 of RfHdr
   double mean_sum;
   int32_t nc;
   int32_t rf_len;
 };
-static_assert(sizeof(RfAcc) == 32 && sizeof(RfAccHead) == 16, "RfAccHead is the head of RfAcc");
+struct RfTop {  // bytes 16..31 of RfHdr
+  double s1;
+  double s2;
+};
+#define RF_HDR_WORDS 6  // doubles of the header; the stack follows
+static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAccHead) == 16 && sizeof(RfTop) == 16, "RfHdr layout");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc
@@ -226,7 +229,6 @@ struct FleetDev {
                       // segment boundary, i.e. at schedule events only
   double* soh;        // [E,N]
   double* soc_deg;    // [E,N] (valid where the INPLANE bit is set)
-  RfTop* rf_top;      // [E,N] (rainflow mode)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
   // device-side data log (FleetParams.log_data; utils/data_logger/data_logger.py:21-68): a ring of `log_cap` rows per env,
@@ -238,9 +240,9 @@ struct FleetDev {
   double* log_env;    // [log_cap][E][4] reward, cashflow, overload_amount, cum_soc_missing (:659-661)
   double* log_ev;     // [log_cap][E][4][N] action, (dis)charging energy (ev_charger.py:114,174), degradation, soh
   float* log_obs;     // [log_cap][E][obs_dim] the (normalised) observation of the row
-  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfAcc (4 doubles) followed by the reversal stack, EV-major
-                      // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators + the
-                      // stack entries around the top) instead of one line per field / stack level
+  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (6 doubles) followed by the reversal stack, EV-major
+                      // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators, stack top
+                      // and the entries below it) instead of one line per field / stack level
   int rf_row_stride;  // doubles per row (multiple of 16)
 };
 

@@ -345,24 +345,21 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
 // three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
 // The stack of the EV always starts at slot 0 (`tail` = its size; when the three-point rule drops the FIRST point -- the
 // stack is exactly [a, b, p] then -- the survivor below the top is rewritten to slot 0, so no head index exists and the size
-// alone describes it).  Its newest entry lives in the RfTop record only, the entries below it in the EV's rainflow row
-// behind the RfAcc header (struct RfTop in fleet_device.h); RfTop also caches the second newest.
+// alone describes it).  Its newest entry lives in the row header only (s2; s1 caches the one below), the entries below it in
+// the stack words behind the header (struct RfHdr in fleet_device.h).
 // The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
-// state machine, knows the new sample, therefore whether a reversal point is pushed and -- from the cached top -- whether
-// that closes a cycle, and REQUESTS what a closure needs of the row (the head of the accumulators and the two entries
-// below the cached ones: one 16-byte load each); `rf_finish`, after the observation stores and the money terms, consumes
-// it.  Sparse accesses are what a push costs (every lane its own cache line): a push that closes nothing is ONE 8-byte
-// store, a push that closes one full cycle two loads and one store, none of them to the stack.
+// state machine, knows the new sample and therefore whether a reversal point is pushed, and REQUESTS the EV's row (header
+// head, stack top, the two entries below the top two: three 16-byte loads of one cache line); `rf_finish`, after the
+// observation stores and the money terms, consumes it.  A step that pushes nothing -- three in four -- never touches the row.
 struct RfReq {
   double p;        // the reversal point to push
-  RfAccHead acc;   // requested when the push closes a cycle
+  RfAccHead acc;   // requested when a point is pushed
+  RfTop top;       // stack[tail-2], stack[tail-1]
   double w0, w1;   // stack[tail-3], [tail-4] (before the push)
-  bool push, closes;
+  bool push;
 };
-__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, const RfTop& top,
-                                         RfReq& q) {
+__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q) {
   q.push = false;
-  q.closes = false;
   q.p = old_deg;
   // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes the previous
   // sample a reversal point
@@ -376,48 +373,36 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old
     sgn = s_next;
   }
   if (q.push) {
-    q.closes = (tail + 1 >= 3) && !(fabs(old_deg - top.s2) < fabs(top.s2 - top.s1));
-#ifdef FLEET_ABL_NO_CLOSE
-    q.closes = false;
-#endif
-    if (q.closes) {
-      const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-#ifdef FLEET_ABL_NO_RFLOADS
-      q.acc.mean_sum = 0.0; q.acc.nc = 0; q.acc.rf_len = 1000000; q.w1 = 0.25; q.w0 = 0.75;
-#else
-      q.acc = *reinterpret_cast<const RfAccHead*>(row);
-      // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
-      const double* w = row + 4 + (tail - 4);  // tail >= 2 here
-      q.w1 = w[0];
-      q.w0 = w[1];
-#endif
-    }
+    const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+    q.acc = *reinterpret_cast<const RfAccHead*>(row);
+    q.top = *reinterpret_cast<const RfTop*>(row + 2);
+    // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
+    const double* w = row + RF_HDR_WORDS + (tail - 4);  // tail >= 1
+    q.w1 = w[0];
+    q.w0 = w[1];
   }
 }
+// `top`: the stack top after the push (only written when a point was pushed)
 __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfReq& q, int& tail, RfTop& top, uint32_t& err) {
   if (!q.push) return;
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  double* stk = row + 4;  // the stack follows the RfAcc header in the same 128-byte-aligned row
+  double* stk = row + RF_HDR_WORDS;
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
   const double p = q.p;
-  double a = top.s1, b = top.s2;  // stack[tail-2] (also in the row), stack[tail-1] (only here)
-  if (!q.closes) {
-#ifndef FLEET_ABL_NO_STKSTORE
-    st_pol<FLEET_ST_RF>(stk + (tail - 1), b);  // the displaced top joins the row; tail >= 1: the episode's first sample is always on the stack
-#endif
-#ifdef FLEET_ABL_NO_CLOSE
-    tail = tail < 6 ? tail + 1 : 3;
-#else
+  double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
+  const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
+  if (!closes) {
+    st_pol<FLEET_ST_RF>(stk + (tail - 1), b);  // the displaced top joins the stack words; tail >= 1
     tail += 1;
-#endif
     top.s1 = b;
     top.s2 = p;
+    st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
     return;
   }
-  int nwin = tail - 2 > 2 ? 2 : tail - 2;  // entries below the cached ones that are in registers
+  int nwin = tail - 2 > 2 ? 2 : tail - 2;  // entries below the top two that are in registers
   const double w0 = q.w0, w1 = q.w1;
   tail += 1;
   const int L = q.acc.rf_len;
@@ -436,7 +421,7 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
     if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
       stk[0] = b;
       tail = 2;
-    } else {  // full cycle, drop its two points -> stack = [..., p]: the row keeps what it has, p lives in the top record
+    } else {  // full cycle, drop its two points -> stack = [..., p]: the stack words keep what they have, p lives in s2
       tail -= 2;
       if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
       else b = stk[tail - 2];
@@ -453,28 +438,28 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
   out.mean_sum = mean_sum;
   out.nc = nc;
   out.rf_len = L;
-#ifndef FLEET_ABL_NO_ACCSTORE
-  st_pol<FLEET_ST_RF>(reinterpret_cast<RfAccHead*>(row), out);
-#endif
-  if (has_csum) reinterpret_cast<RfAcc*>(row)->csum += dcsum;
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
+  st_pol<FLEET_ST_RF>(reinterpret_cast<RfAccHead*>(row), out);
+  st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
+  if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
 }
 
 // RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
 // `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, const RfTop& top, uint32_t& err,
-                                             double dt_hours) {
+// `top` / `have_top`: the stack top when this step's push has just written it (registers are newer than the row).
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, const RfTop& top, bool have_top,
+                                             uint32_t& err, double dt_hours) {
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  const double* stk = row + 4;
+  const double* stk = row + RF_HDR_WORDS;
   // everything this needs from memory is requested up front (one round trip)
-  RfAcc acc = *reinterpret_cast<RfAcc*>(row);
+  const RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
   SeiRec sr = d.sei[i];
-  const int L = acc.rf_len;
-  const int nc = acc.nc;
-  const double mean_sum0 = acc.mean_sum, csum0 = acc.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
+  const int L = hd.rf_len;
+  const int nc = hd.nc;
+  const double mean_sum0 = hd.mean_sum, csum0 = hd.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
   const double st = d.stress_temp;
 #ifdef FLEET_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,7 +484,7 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
     int vt = tail, vh = 0;
     int size = vt - vh + 1;
-    double a = top.s1, b = top.s2;
+    double a = have_top ? top.s1 : hd.s1, b = have_top ? top.s2 : hd.s2;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -542,9 +527,12 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     sr.fd_cyc = fd_cyc;
     sr.fd_cal = fd_cal;
     sr.sei_l = sei_l;
-    acc.rf_len = len;
-    acc.csum = 0.0;  // every closed cycle so far now lies below the new rainflow_length-1
-    *reinterpret_cast<RfAcc*>(row) = acc;
+    RfAccHead out;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
+    out.mean_sum = mean_sum0;
+    out.nc = nc;
+    out.rf_len = len;
+    *reinterpret_cast<RfAccHead*>(row) = out;
+    reinterpret_cast<RfHdr*>(row)->csum = 0.0;
   }
   FLEET_STAMP(13);  // SEI model evaluated
   const double s = sei_soh0 - degradation;
@@ -627,16 +615,14 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     d.run[i] = s1;
     d.soh[i] = soh;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-      RfTop top;
-      top.s1 = 0.0;
-      top.s2 = soc_deg;
-      d.rf_top[i] = top;
-      RfAcc acc = *reinterpret_cast<RfAcc*>(row);  // rainflow_length survives
-      acc.mean_sum = 0.0;
-      acc.csum = 0.0;
-      acc.nc = 0;
-      *reinterpret_cast<RfAcc*>(row) = acc;  // the stack is [soc_deg]: its only entry lives in the top record
+      RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
+      RfHdr hd = *hp;  // rainflow_length survives
+      hd.mean_sum = 0.0;
+      hd.csum = 0.0;
+      hd.nc = 0;
+      hd.s1 = 0.0;
+      hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
+      *hp = hd;
     }
     const AuxRec ar = d.aux_tab[(size_t)start * N + c];
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
@@ -691,10 +677,12 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // stores of the state records that changed.
 template <int DEG, bool WIDE>
 __device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
-                                          int tail, int sgn, RfTop top, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
+                                          int tail, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
                                           bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
-                                          size_t lrow, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail, RfTop& sei_top) {
+                                          size_t lrow, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail, RfTop& sei_top,
+                                          bool& sei_have_top) {
   double soh = soh0;
+  RfTop top = {0.0, 0.0};
   if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, err);
   const bool pushed = rq.push;
   if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
@@ -703,6 +691,7 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, in
     sei_soh = soh0;
     sei_tail = tail;
     sei_top = top;
+    sei_have_top = pushed;
   }
   if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
     double* lev = d.log_ev + lrow * 4 * N + c;
@@ -720,14 +709,6 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, in
 #endif
     if (crosses) st_rec16(d.run + i, nr);  // the next launch advances into another segment of the EV's schedule
     if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
-    // the cached stack top only changes when a reversal point was pushed
-#ifndef FLEET_ABL_NO_TOPSTORE
-#ifdef FLEET_TOP_ALWAYS  // experiment: whole lines instead of the pushing lanes' 16-byte pieces
-    if (DEG == FLEET_DEG_RAINFLOW) st_pol<FLEET_ST_RF>(d.rf_top + i, top);
-#else
-    if (DEG == FLEET_DEG_RAINFLOW && pushed) st_pol<FLEET_ST_RF>(d.rf_top + i, top);
-#endif
-#endif
   }
 }
 
@@ -746,7 +727,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     // its lanes' state records and action, E and N for their addresses -- is passed here once more, ahead of the argument
     // block, so that those loads do not wait for an argument fetch.
     const Hot* __restrict__ p_hot, const SegRec* __restrict__ p_run, const double* __restrict__ p_soh,
-    const RfTop* __restrict__ p_rf_top, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* __restrict__ p_env,
+    const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* __restrict__ p_env,
     FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
@@ -771,7 +752,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
   Hot h_pre = {0.0, 0.0f, 0u};
   SegRec run_pre = {0.0, 0u, 0u};
   double soh_pre = 0.0;
-  RfTop top_pre = {0.0, 0.0};
   float a32_pre = 0.0f;
   double a64_pre = 0.0;
   if (kEarly) {
@@ -785,9 +765,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     if (A64) a64_pre = ((const double*)p_actions)[i0];
     else a32_pre = ((const float*)p_actions)[i0];
     run_pre = p_run[i0];
-#ifndef FLEET_ABL_NO_TOPLOAD
-    if (DEG == FLEET_DEG_RAINFLOW) top_pre = p_rf_top[i0];
-#endif
   }
 
   EnvHead r = p_env[e].h;
@@ -913,6 +890,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     double sei_sample = 0.0, sei_soh = 0.0;
     int sei_tail = 0;
     RfTop sei_top = {0.0, 0.0};
+    bool sei_have_top = false;
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     // one EV per lane and one step per launch: the tail of the EV's step (rainflow push, state stores) is deferred until
     // after the per-env reductions, so that the push's memory round trip has them to hide behind as well
@@ -925,8 +903,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     int lt_c = 0, lt_tail = 0, lt_sgn = 0;
     RfReq lt_rq;
     lt_rq.push = false;
-    lt_rq.closes = false;
-    RfTop lt_top = {0.0, 0.0};
     double lt_soc = 0.0, lt_soc_deg = 0.0, lt_old_deg = 0.0, lt_soh0 = 0.0;
     float lt_hl = 0.0f;
     uint32_t lt_there = 0;
@@ -938,8 +914,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       const Hot hb = kEarly ? h_pre : d.hot[i];
       const SegRec rr = kEarly ? run_pre : d.run[i];  // schedule record of row t1
       const double soh0 = kEarly ? soh_pre : d.soh[i];
-      RfTop top = {0.0, 0.0};
-      if (DEG == FLEET_DEG_RAINFLOW) top = kEarly ? top_pre : d.rf_top[i];
       // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
       AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifndef FLEET_ABL_NO_AUXLOAD
@@ -1046,7 +1020,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
       RfReq rq;
       rq.push = false;
-      if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, top, rq);
+      if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
@@ -1069,7 +1043,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         lt_rq = rq;
         lt_tail = tail;
         lt_sgn = sgn;
-        lt_top = top;
         lt_soc = soc;
         lt_soc_deg = soc_deg;
         lt_old_deg = old_deg;
@@ -1083,8 +1056,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         lt_valid = true;
         break;
       }
-      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, top, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
-                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top);
+      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
+                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -1133,9 +1106,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
     }
     if (kLate && lt_valid)
-      ev_finish<DEG, WIDE>(d, lt_i, lt_c, N, env_ok, deg_row, dt_step, lt_rq, lt_tail, lt_sgn, lt_top, lt_soc, lt_soc_deg, lt_old_deg, lt_hl,
+      ev_finish<DEG, WIDE>(d, lt_i, lt_c, N, env_ok, deg_row, dt_step, lt_rq, lt_tail, lt_sgn, lt_soc, lt_soc_deg, lt_old_deg, lt_hl,
                            lt_there, lt_t090, lt_inplane, lt_crosses, lt_nr, lt_soh0, 0.0, 0.0, false, 0, err, sei_sample, sei_soh, sei_tail,
-                           sei_top);
+                           sei_top, sei_have_top);
     FLEET_STAMP(7);
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
@@ -1146,13 +1119,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         const size_t i = (size_t)e * N + c;
         double deg, soh_new;
         if (!WIDE) {
-          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, err, dt_step);
+          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step);
           soh_new = sei_soh - deg;
         } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
           const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
-          const RfTop top = d.rf_top[i];
-          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), top, err, dt_step);
+          const RfTop none = {0.0, 0.0};
+          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
           soh_new = d.soh[i] - deg;
         }
         d.soh[i] = soh_new;
@@ -1251,7 +1224,7 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_SOC_DEG: ((double*)out)[i] = HOT_INPLANE(d.hot[i].bits) ? d.soc_deg[i] : d.hot[i].x; break;
     case FLEET_F_TARGET_SOC: ((double*)out)[i] = HOT_T090(d.hot[i].bits) ? 0.9 : d.target_soc; break;
     case FLEET_F_RF_LEN:
-      ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfAcc*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;
+      ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;
       break;
     case FLEET_F_FD_CYC: ((double*)out)[i] = d.sei[i].fd_cyc; break;
     case FLEET_F_FD_CAL: ((double*)out)[i] = d.sei[i].fd_cal; break;
@@ -1329,7 +1302,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-#define FLEET_PRE_ARGS d.hot, d.run, d.soh, d.rf_top, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords preloaded) */
+#define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
