@@ -93,16 +93,18 @@ def kernel_source_sha() -> str:
 
 
 def committed_traffic(config: str, envs: int, evs: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
-    profiles/r02_traffic_<config>.json); None when the profile is absent, was taken on another kernel source or shape."""
-    for name in (f"r02_traffic_{config}.json", f"r02_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
+    """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
+    profiles/r03_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
+    The counters need rocprofv3, so they cannot be read inside this run: the figure is looked up, and `traffic_source` says so."""
+    for name in (f"r03_traffic_{config}.json", f"r03_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.isfile(path):
             continue
         t = json.load(open(path))
         if t.get("kernel_src_sha") == kernel_source_sha() and (t.get("envs"), t.get("evs"), t.get("config")) == (envs, evs, config):
-            return t.get("hbm_bytes_per_launch")
-    return None
+            return t.get("hbm_bytes_per_launch"), (f"profiles/{name}: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes of "
+                                                   "this command on this kernel source (tools/prof_traffic.sh)")
+    return None, "no committed rocprofv3 PMC profile for this kernel source and shape"
 
 
 def cpu_baseline(params, tables, time_feat, n_evs: int, budget_s: float = 8.0):
@@ -187,6 +189,26 @@ class Group:
                                 use_graph=use_graph)
 
 
+def self_launch(n: int) -> int:
+    """Run this command under `torch.distributed.run` with one rank per GPU; returns the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif res.stdout:
+        sys.stderr.write(res.stdout[-4000:])
+    return res.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,7 +229,15 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
     ap.add_argument("--deg", default=None, choices=["none", "linear", "rainflow"],
                     help="override the config's degradation model (diagnostics)")
+    ap.add_argument("--reps", type=int, default=None,
+                    help="timed regions of exactly --steps launches each, run back to back; the median region is reported "
+                         "(default: 31 for runs of up to 256 steps, else 7)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (nothing in this process
+    # has touched the GPU yet -- a process that has must never exec another program on this pool), relay its JSON line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -224,7 +254,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ  # under torch.distributed.run: the collectives run even with one rank (RCCL smoke test)
+    if launched:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
@@ -271,25 +302,37 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the timed region: exactly K steps between two barriers -----------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for g in groups:
-        g.batch.timer_start()
-    run(args.steps)
-    for g in groups:
-        g.batch.timer_mark()
-    ev_ms = [g.batch.timer_read() for g in groups]  # HIP events on the streams the kernels run on (each read waits for its stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        w = torch.tensor([wall], device=cdev, dtype=torch.float64)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
+    # ---- the timed regions: each is exactly K steps between two barriers ------------------------------------------------------
+    # One region is what the contract describes (barrier + synchronize, K launches, synchronize + barrier).  A single region of
+    # a short run mostly measures the host's wake-up after the synchronize (tens of microseconds against 20 launches of 9 us), so
+    # R regions are run back to back and the MEDIAN one is reported (`reps`, with the fastest and slowest beside it); inside a
+    # region the wait for the device is a spin on hipStreamQuery instead of a blocking synchronize.
+    reps = args.reps if args.reps else (31 if args.steps <= 256 else 7)
+    walls, ev_regions = [], []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for g in groups:
+            g.batch.timer_start()
+        run(args.steps)
+        for g in groups:
+            g.batch.timer_mark()
+        for g in groups:
+            g.batch.spin_wait()
+        barrier()
+        walls.append(time.perf_counter() - t0)
+        ev_regions.append([g.batch.timer_read() for g in groups])  # HIP events on the streams the kernels run on
+    w = torch.tensor(walls, device=cdev, dtype=torch.float64)
+    if launched:
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
+    walls = [float(x) for x in w.cpu()]
+    order = sorted(range(reps), key=lambda i: walls[i])
+    mid = order[reps // 2]
+    wall, ev_ms = walls[mid], ev_regions[mid]
     # ---- logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1) ------------------
     t1 = time.perf_counter()
     off = 0
@@ -330,6 +373,8 @@ def main():
         if check:
             g0.batch.check_errors()
         fleets = "+".join(g.use_case for g in groups)
+        traffic, traffic_source = (committed_traffic(args.config, E, N) if not (args.deg or args.use_case)
+                                   else (None, "diagnostic override of the workload"))
         graph_used = use_graph and args.steps >= L
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
@@ -337,6 +382,7 @@ def main():
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
+            "reps": reps, "ms_per_step_min": min(walls) * 1e3 / args.steps, "ms_per_step_max": max(walls) * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{E} envs x {N} EVs per GPU, {fleets} fleet{'s (one third each)' if len(groups) > 1 else ''}, "
@@ -348,7 +394,7 @@ def main():
                        "launch": (f"hipGraph of {L} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": committed_traffic(args.config, E, N) if not (args.deg or args.use_case) else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name(N, spec["deg"]), "kernel_ms": k_ms,
                          "kernel_src_sha": kernel_source_sha(),
                          "algorithmic_bytes_per_env_step": bytes_launch / E, "bytes_per_launch": bytes_launch,
@@ -358,7 +404,7 @@ def main():
             "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * reps / (many_ms * 1e-3),
                           "algorithmic_bytes_per_env_step": g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K,
                           "GBps": (g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K) * g0.E * K * reps / (many_ms * 1e-3) / 1e9},
-            "log_gather_ms": gather_ms,
+            "log_gather_ms": gather_ms, "collective_backend": (args.backend if launched else None),
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
         if not args.no_host_path and world == 1:
@@ -367,7 +413,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g0.params, g0.tables, g0.tf, N)
     for g in groups:
         g.batch.close()
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
@@ -378,11 +424,11 @@ def host_path(g0, groups, budget_s: float = 1.5):
     """The host-pointer path, PCIe both ways, as an SB3 loop sees it (never the headline value): `fleet_step_host` through
     FleetBatch.step with NumPy buffers, bounded to about a second."""
     acts = g0.tape[:8].cpu().numpy()
-    g0.batch.step(acts[0])
+    g0.batch.step(acts[0], copy=False)
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < budget_s:
-        g0.batch.step(acts[n % 8])
+        g0.batch.step(acts[n % 8], copy=False)  # the pinned transfer buffer itself (SB3 copies what it keeps)
         n += 1
     dt = time.perf_counter() - t0
     return {"env_steps_per_s": g0.E * n / dt, "ms_per_step": dt * 1e3 / n, "envs": g0.E,

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -175,6 +175,10 @@ def load_library():
     lib.fleet_last_error.restype = C.c_char_p
     lib.fleet_set_stream.argtypes = [vp, vp]
     lib.fleet_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.fleet_use_own_stream.argtypes = [vp]
+    lib.fleet_stream_query.argtypes = [vp]
+    lib.fleet_stream_query.restype = C.c_int
+    lib.fleet_log_dropped.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.fleet_log_capacity.argtypes = [vp]
     lib.fleet_log_read.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.fleet_log_clear.argtypes = [vp]
@@ -201,7 +205,8 @@ def load_library():
     lib.fleet_timer_read.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
-    for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_log_capacity", "fleet_log_read",
+    for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_use_own_stream", "fleet_log_dropped",
+                 "fleet_log_capacity", "fleet_log_read",
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
@@ -213,8 +218,8 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = (
-    "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_get_stream", "fleet_synchronize",
-    "fleet_log_capacity", "fleet_log_read", "fleet_log_clear",
+    "fleet_obs_dim", "fleet_create", "fleet_destroy", "fleet_last_error", "fleet_set_stream", "fleet_get_stream", "fleet_use_own_stream",
+    "fleet_synchronize", "fleet_stream_query", "fleet_log_capacity", "fleet_log_dropped", "fleet_log_read", "fleet_log_clear",
     "fleet_set_start_schedule", "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev",
     "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",

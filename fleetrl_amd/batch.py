@@ -18,6 +18,32 @@ from ._capi import FleetHipError
 __all__ = ["FleetBatch", "FleetHipError"]
 
 
+class _PinnedBuffer:
+    """Owner of one `fleet_host_alloc` block.  The NumPy arrays handed out are views of a ctypes array that holds a
+    reference to this object, so the block is freed when the LAST view of it dies -- not when the batch is closed or
+    collected (an observation returned by step() stays valid for as long as the caller keeps it)."""
+
+    def __init__(self, lib, nbytes: int):
+        out = C.c_void_p()
+        rc = lib.fleet_host_alloc(int(nbytes), C.byref(out))
+        if rc != _capi.OK or not out.value:
+            raise FleetHipError(rc, "fleet_host_alloc failed")
+        self._lib, self.address, self.nbytes = lib, int(out.value), int(nbytes)
+
+    def array(self, shape, dtype) -> np.ndarray:
+        raw = (C.c_char * self.nbytes).from_address(self.address)
+        raw._fleet_owner = self  # the view -> ctypes array -> owner chain keeps the block alive
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.address:
+                self._lib.fleet_host_free(C.c_void_p(self.address))
+                self.address = 0
+        except Exception:
+            pass
+
+
 class FleetBatch:
     def __init__(self, params: _capi.FleetParams, tables, time_feat: np.ndarray | None = None, device: int = 0):
         self.lib = _capi.load_library()
@@ -33,8 +59,8 @@ class FleetBatch:
         self.E, self.N = int(params.num_envs), int(params.num_cars)
         self.obs_dim = int(self.lib.fleet_obs_dim(C.byref(params)))
         self._term = None
-        self._pinned = []      # (address, numpy view) of the pinned observation buffers handed out by step()
-        self._pin_next = 0
+        self._obs_ring = []    # pinned observation buffers step() lands its transfer in, used in turn (own list: never
+        self._obs_next = 0     # mixed with the caller's pinned_array() buffers)
 
     # ------------------------------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -45,21 +71,14 @@ class FleetBatch:
         if getattr(self, "h", None):
             self.lib.fleet_destroy(self.h)
             self.h = None
-        for addr, _view in getattr(self, "_pinned", []):
-            self.lib.fleet_host_free(C.c_void_p(addr))
-        self._pinned = []
+        self._obs_ring = []  # the blocks themselves live as long as any view of them (see _PinnedBuffer)
 
     def pinned_array(self, shape, dtype=np.float32) -> np.ndarray:
         """A NumPy array in pinned (page-locked) host memory (`fleet_host_alloc`): the host entry points move such buffers
-        over PCIe without staging.  Owned by this batch: valid until close()."""
+        over PCIe without staging.  The memory is freed when the last view of the array is gone (independent of this batch's
+        lifetime)."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        out = C.c_void_p()
-        rc = self.lib.fleet_host_alloc(n, C.byref(out))
-        if rc != _capi.OK:
-            raise FleetHipError(rc, "fleet_host_alloc failed")
-        view = np.frombuffer((C.c_char * n).from_address(out.value), dtype=dtype).reshape(shape)
-        self._pinned.append((out.value, view))
-        return view
+        return _PinnedBuffer(self.lib, n).array(shape, dtype)
 
     def __del__(self):
         try:
@@ -70,8 +89,22 @@ class FleetBatch:
     def synchronize(self):
         self._check(self.lib.fleet_synchronize(self.h))
 
+    def spin_wait(self):
+        """Wait for the handle's stream by polling (hipStreamQuery): returns within microseconds of the last launch's end,
+        where a blocking synchronize pays the host's wake-up latency (bench.py's short timed regions)."""
+        while True:
+            rc = self.lib.fleet_stream_query(self.h)
+            if rc == 0:
+                return
+            if rc != -1:
+                self._check(rc)
+
     def set_stream(self, hip_stream: int):
         self._check(self.lib.fleet_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def use_own_stream(self):
+        """Back to the handle's own (non-blocking) stream after `set_stream` / `use_torch_stream`."""
+        self._check(self.lib.fleet_use_own_stream(self.h))
 
     def stream_ptr(self) -> int:
         """The hipStream_t the handle launches on (an integer address)."""
@@ -107,6 +140,12 @@ class FleetBatch:
                                              None if obs is None else obs.ctypes.data))
         return {"pos": pos, "row": row, "env": env, "ev": ev, "obs": obs, "capacity": cap}
 
+    def log_dropped(self) -> int:
+        """Rows the ring has already overwritten, summed over the envs (0 = get_log() is complete)."""
+        n = C.c_int64()
+        self._check(self.lib.fleet_log_dropped(self.h, C.byref(n)))
+        return int(n.value)
+
     def log_clear(self):
         self._check(self.lib.fleet_log_clear(self.h))
 
@@ -139,19 +178,21 @@ class FleetBatch:
 
     OBS_RING = 4  # pinned observation buffers step() cycles through
 
-    def step(self, actions, fresh_obs: bool = False):
+    def step(self, actions, copy: bool = True):
         """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim]); `terminal_obs` is a buffer
-        reused between calls whose rows are valid only where `done` is set.  `obs` is one of OBS_RING pinned buffers used in
-        turn (the transfer lands in it directly): it stays valid for the next OBS_RING - 1 calls -- enough for an SB3 /
-        gymnasium loop, which holds the previous observation while it steps -- pass `fresh_obs=True` for a private copy."""
+        reused between calls whose rows are valid only where `done` is set.
+        The observation transfer lands in one of OBS_RING pinned buffers used in turn.  `copy=True` (default) returns a private
+        copy of it, like the reference's env returns a fresh array every step.  `copy=False` returns the pinned buffer itself
+        (no 4 * E * obs_dim byte copy on the host): it is overwritten OBS_RING calls later -- enough for an SB3 loop, which
+        holds the previous observation while it steps and copies what it keeps; not for code that collects observations in a
+        list.  Either way the memory stays valid for as long as the returned array is referenced."""
         a, dt = self._act(actions, (self.E, self.N))
-        if fresh_obs:
-            obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
-        else:
-            if len(self._pinned) < self.OBS_RING:
-                self.pinned_array((self.E, self.obs_dim))
-            obs = self._pinned[self._pin_next % self.OBS_RING][1]
-            self._pin_next += 1
+        if len(self._obs_ring) < self.OBS_RING:
+            self._obs_ring.append(self.pinned_array((self.E, self.obs_dim)))
+        obs = self._obs_ring[self._obs_next % len(self._obs_ring)]
+        self._obs_next += 1
+        if obs.shape != (self.E, self.obs_dim) or obs.dtype != np.float32:  # what fleet_step_host will write
+            raise FleetHipError(_capi.ERR_INVALID, "internal: observation buffer of the wrong shape")
         if self._term is None:  # reused across steps: only the rows of envs that just finished are meaningful
             self._term = np.zeros((self.E, self.obs_dim), dtype=np.float32)
         term = self._term
@@ -159,7 +200,7 @@ class FleetBatch:
         done = np.empty(self.E, dtype=np.uint8)
         self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,
                                               done.ctypes.data, term.ctypes.data))
-        return obs, rew, done, term
+        return (obs.copy() if copy else obs), rew, done, term
 
     def last_step_episodes(self):
         """(env indices, returns, lengths) of the episodes that ended in the last `step()` -- already on the host, no launch."""

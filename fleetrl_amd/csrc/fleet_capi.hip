@@ -22,8 +22,8 @@ struct Batch {
   FleetParams p{};
   FleetDev d{};
   int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
+  hipStream_t stream = nullptr;      // the stream launches go to: the handle's own one, or an adopted one (fleet_set_stream)
+  hipStream_t own_stream = nullptr;  // created with the handle, destroyed with it; never handed out of the library's control
   std::string error;
   std::vector<void*> allocs;
   // staging for the *_host entry points
@@ -342,8 +342,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   b->p = *p;
   b->device = device;
   HIP_TRY(b, hipSetDevice(device));
-  HIP_TRY(b, hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  b->own_stream = true;
+  HIP_TRY(b, hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+  b->stream = b->own_stream;
   HIP_TRY(b, hipEventCreate(&b->ev_start));
   HIP_TRY(b, hipEventCreate(&b->ev_stop));
 
@@ -539,7 +539,7 @@ int fleet_create(const FleetParams* p, const FleetTables* t, int device, fleet_h
 int fleet_destroy(fleet_handle h) {
   if (!h) return FLEET_OK;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   for (void* ptr : h->allocs) (void)hipFree(ptr);
   for (void* ptr : {(void*)h->pin_small, h->pin_actions, (void*)h->pin_term})
@@ -547,7 +547,7 @@ int fleet_destroy(fleet_handle h) {
   if (h->dev_sched) (void)hipFree(h->dev_sched);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
-  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return FLEET_OK;
 }
@@ -556,11 +556,21 @@ const char* fleet_last_error(fleet_handle h) { return h ? h->error.c_str() : g_c
 
 int fleet_set_stream(fleet_handle h, void* hip_stream) {
   if (!h) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // what was enqueued on the stream in use so far is finished before the switch
+  drop_graph(h);
+  // the handle's own stream is kept (fleet_set_stream(h, fleet_own_stream) or a later fleet_use_own_stream goes back to it);
+  // an adopted stream is only borrowed: the caller keeps it alive while the handle uses it
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  return FLEET_OK;
+}
+
+int fleet_use_own_stream(fleet_handle h) {
+  if (!h) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drop_graph(h);
-  if (h->own_stream) (void)hipStreamDestroy(h->stream);
-  h->stream = static_cast<hipStream_t>(hip_stream);
-  h->own_stream = false;
+  h->stream = h->own_stream;
   return FLEET_OK;
 }
 
@@ -568,6 +578,18 @@ int fleet_synchronize(fleet_handle h) {
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return FLEET_OK;
+}
+
+int fleet_stream_query(fleet_handle h) {
+  if (!h) return FLEET_ERR_INVALID;
+  const hipError_t e = hipStreamQuery(h->stream);
+  if (e == hipSuccess) return FLEET_OK;
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  h->error = std::string("hipStreamQuery: ") + hipGetErrorString(e);
+  return FLEET_ERR_HIP;
 }
 
 int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episodes) {
@@ -825,6 +847,21 @@ int fleet_get_dist_factor(fleet_handle h, double* out) {
 
 int fleet_log_capacity(fleet_handle h) { return (h && h->d.log_pos) ? h->d.log_cap : 0; }
 
+int fleet_log_dropped(fleet_handle h, int64_t* rows) {
+  if (!h || !rows || !h->d.log_pos) {
+    if (h) h->error = "fleet_log_dropped: the data log is off or a null pointer";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<int32_t> pos((size_t)h->d.E);
+  HIP_TRY(h, hipMemcpyAsync(pos.data(), h->d.log_pos, pos.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int64_t n = 0;
+  for (int32_t p : pos) n += p > h->d.log_cap ? p - h->d.log_cap : 0;
+  *rows = n;
+  return FLEET_OK;
+}
+
 int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs) {
   if (!h || !h->d.log_pos) {
     if (h) h->error = "fleet_log_read: the data log is off (FleetParams.log_data = 0)";
@@ -914,17 +951,20 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
     if (stale) {
       drop_graph(h);
       hipGraph_t graph = nullptr;
-      HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      // capture is not allowed on the legacy null stream (what torch's default stream is): record on the handle's own
+      // stream then; the graph itself is launched on the stream in use
+      hipStream_t cap = h->stream ? h->stream : h->own_stream;
+      HIP_TRY(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
       for (int k = 0; k < tape_len; ++k) {
-        hipError_t e = fleet_launch_step(h->d, base + (size_t)k * row, act_dtype, 1, obs, reward, done, nullptr, nullptr, h->stream);
+        hipError_t e = fleet_launch_step(h->d, base + (size_t)k * row, act_dtype, 1, obs, reward, done, nullptr, nullptr, cap);
         if (e != hipSuccess) {
-          (void)hipStreamEndCapture(h->stream, &graph);
+          (void)hipStreamEndCapture(cap, &graph);
           if (graph) (void)hipGraphDestroy(graph);
           h->error = std::string("capture: ") + hipGetErrorString(e);
           return FLEET_ERR_HIP;
         }
       }
-      HIP_TRY(h, hipStreamEndCapture(h->stream, &graph));
+      HIP_TRY(h, hipStreamEndCapture(cap, &graph));
       hipError_t e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) {

@@ -956,6 +956,15 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       SegRec nr = rr;
       if (crosses) nr = d.seg[(size_t)t2 * N + c];
       const RowRec tb1 = seg_row(rr, t1, d.dt);
+#ifdef FLEET_PAD_VALU_A  // diagnostic: N dependent-free float64 FMAs right where the charge arithmetic starts
+      {
+        double p0 = hb.x, p1 = soh0, p2 = a, p3 = hb.x + 1.0;
+#pragma unroll
+        for (int z = 0; z < FLEET_PAD_VALU_A / 4; ++z)
+          asm volatile("v_fma_f64 %0, %0, %0, %1\n v_fma_f64 %1, %1, %1, %2\n v_fma_f64 %2, %2, %2, %3\n v_fma_f64 %3, %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        if (p0 + p1 + p2 + p3 == 1.2345e-300) err |= 1u << 30;
+      }
+#endif
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
       double soc = HOT_SOC(hb);
       float hl = hb.hl;
@@ -1018,9 +1027,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
       // here and consumed after the observation stores and the money terms
       int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+      // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
+      // stores would cost the multi-step kernel a resident wavefront per SIMD)
+      constexpr bool kSplitRf = !MULTI;
       RfReq rq;
       rq.push = false;
-      if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
+      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
@@ -1037,6 +1049,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
+      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
       if (kLate) {  // one EV per lane: the rest of the EV's step runs after the per-env reductions (below)
         lt_i = i;
         lt_c = c;
@@ -1064,6 +1077,15 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
+#ifdef FLEET_PAD_VALU_B  // diagnostic: the same after the EV body, before the reductions
+    {
+      double p0 = cash, p1 = rew, p2 = asum, p3 = cash + 1.0;
+#pragma unroll
+      for (int z = 0; z < FLEET_PAD_VALU_B / 4; ++z)
+        asm volatile("v_fma_f64 %0, %0, %0, %1\n v_fma_f64 %1, %1, %1, %2\n v_fma_f64 %2, %2, %2, %3\n v_fma_f64 %3, %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+      if (p0 + p1 + p2 + p3 == 1.2345e-300) err |= 1u << 30;
+    }
+#endif
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
 #ifndef FLEET_ABL_NO_REDUCE

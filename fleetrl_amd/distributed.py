@@ -36,7 +36,7 @@ def gather_episode_stats(returns, lengths, group=None, equal_shards: bool = Fals
     as_numpy = isinstance(returns, np.ndarray)
     r = torch.as_tensor(returns, dtype=torch.float64)
     n = torch.as_tensor(lengths, dtype=torch.int32)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return (r.numpy(), n.numpy()) if as_numpy else (r, n)
     world = dist.get_world_size(group)
     if equal_shards:

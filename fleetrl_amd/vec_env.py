@@ -79,36 +79,41 @@ class FleetCore:
 
         lg = self.batch.log_read()
         cap, pm, N = lg["capacity"], self.rc.price_multiplier, self.num_cars
-        hour, minute = self.tables.hour, self.tables.minute
+        hour, minute = np.asarray(self.tables.hour), np.asarray(self.tables.minute)
+        dropped = int(np.maximum(lg["pos"].astype(np.int64) - cap, 0).sum())
+        if dropped:
+            import warnings
+
+            warnings.warn(f"get_log: the device-side log ring (log_capacity = {cap} rows per env) has overwritten {dropped} rows; "
+                          "the reference's DataLogger is unbounded -- pass a larger `log_capacity` to keep every row", RuntimeWarning)
+        lane = np.arange(N)
         frames = []
-        for i in range(self.num_envs):
+        for i in range(self.num_envs):  # one vectorised pass over the env's rows; the DataFrame itself is per env
             pos = int(lg["pos"][i])
-            rows = []
-            for k in range(max(0, pos - cap), pos):
-                sl = k % cap
-                raw = int(lg["row"][sl, i])
-                is_reset, t = raw < 0, raw & 0x7FFFFFFF
-                rew, cash, over, miss = (float(x) for x in lg["env"][sl, i])
-                act, energy, deg, soh = lg["ev"][sl, i]
-                if is_reset:
-                    charge_log, degradation, penalty = np.zeros(N), 0.0, 0.0
-                else:
-                    charge_log = np.zeros(N)
-                    ce = de = 0.0
-                    for c in range(N):  # quirk Q8: the two energies are not cleared from car to car
-                        if act[c] >= 0:
-                            ce = energy[c]
-                        else:
-                            de = energy[c]
-                        charge_log[c] = ce + de
-                    deg_row = self.rc.calc_deg and hour[t] == 14 and minute[t] == 45
-                    degradation = deg.copy() if deg_row else 0.0
-                    penalty = rew - cash * pm
-                rows.append({"Episode": k // self._log_episode_len + 1, "Time": self._stamp(t), "Observation": lg["obs"][sl, i].copy(),
-                             "Action": act.copy(), "Reward": rew, "Cashflow": cash, "Penalties": penalty,
-                             "Grid overloading": abs(over), "SOC violation": abs(miss), "Degradation": degradation,
-                             "Charging energy": charge_log, "SOH": soh.copy()})
-            frames.append(pd.DataFrame(rows))
+            ks = np.arange(max(0, pos - cap), pos)
+            sl = ks % cap
+            raw = lg["row"][sl, i].astype(np.int64)
+            is_reset = raw < 0
+            t = raw & 0x7FFFFFFF
+            envv = lg["env"][sl, i]                      # [rows, 4]: reward, cashflow, overload, SOC missing
+            act, energy, deg, soh = (lg["ev"][sl, i, j] for j in range(4))   # [rows, N] each
+            obs = lg["obs"][sl, i]
+            # quirk Q8: charging_energy / discharging_energy are not cleared from car to car, so each car logs the energy of the
+            # last car (itself included) with a charge action plus that of the last car with a discharge action
+            last_c = np.maximum.accumulate(np.where(act >= 0, lane, -1), axis=1)
+            last_d = np.maximum.accumulate(np.where(act < 0, lane, -1), axis=1)
+            ce = np.where(last_c >= 0, np.take_along_axis(energy, np.maximum(last_c, 0), axis=1), 0.0)
+            de = np.where(last_d >= 0, np.take_along_axis(energy, np.maximum(last_d, 0), axis=1), 0.0)
+            charge_log = np.where(is_reset[:, None], 0.0, ce + de)
+            deg_row = (~is_reset) & bool(self.rc.calc_deg) & (hour[t] == 14) & (minute[t] == 45)
+            rew, cash = envv[:, 0], envv[:, 1]
+            penalty = np.where(is_reset, 0.0, rew - cash * pm)
+            degradation = [deg[r].copy() if deg_row[r] else 0.0 for r in range(len(ks))]
+            frames.append(pd.DataFrame({
+                "Episode": ks // self._log_episode_len + 1, "Time": [self._stamp(x) for x in t], "Observation": list(obs.copy()),
+                "Action": list(act.copy()), "Reward": rew, "Cashflow": cash, "Penalties": penalty,
+                "Grid overloading": np.abs(envv[:, 2]), "SOC violation": np.abs(envv[:, 3]), "Degradation": degradation,
+                "Charging energy": list(charge_log), "SOH": list(soh.copy())}))
         return frames
 
     def clear_log(self):
@@ -157,6 +162,9 @@ class FleetVecEnv:
     """stable-baselines3 `VecEnv` duck type over one fused GPU batch."""
 
     def __init__(self, env_config, num_envs: int, **kw):
+        # copy_obs=True: step() returns a fresh observation array like SubprocVecEnv does; False: the pinned transfer buffer
+        # itself (overwritten four steps later; saves a 4 * num_envs * obs_dim byte host copy per step, see FleetBatch.step)
+        self.copy_obs = bool(kw.pop("copy_obs", True))
         self.core = FleetCore(env_config, num_envs, auto_reset=True, **kw)
         self.num_envs = self.core.num_envs
         self.observation_space = self.core.single_observation_space
@@ -177,7 +185,7 @@ class FleetVecEnv:
 
     def step_wait(self):
         acts = np.asarray(self._actions).reshape(self.num_envs, -1)
-        obs, rew, done, term = self.core.batch.step(acts)
+        obs, rew, done, term = self.core.batch.step(acts, copy=self.copy_obs)
         dones = done.astype(bool)
         # the reference's info is always {} (:235): the envs that did not finish share ONE empty dict per step (4096 dict
         # allocations per step cost more than the step); an env that finished gets a dict of its own
@@ -273,6 +281,7 @@ class FleetVectorEnv:
     """gymnasium vector-env signature (what RLlib / CleanRL style loops expect)."""
 
     def __init__(self, env_config, num_envs: int, **kw):
+        self.copy_obs = bool(kw.pop("copy_obs", True))  # see FleetVecEnv
         self.core = FleetCore(env_config, num_envs, auto_reset=True, **kw)
         self.num_envs = self.core.num_envs
         self.single_observation_space = self.core.single_observation_space
@@ -286,7 +295,7 @@ class FleetVectorEnv:
         return self.core.batch.reset(), {}
 
     def step(self, actions):
-        obs, rew, done, term = self.core.batch.step(np.asarray(actions).reshape(self.num_envs, -1))
+        obs, rew, done, term = self.core.batch.step(np.asarray(actions).reshape(self.num_envs, -1), copy=self.copy_obs)
         terminated = done.astype(bool)
         truncated = np.zeros(self.num_envs, dtype=bool)  # the reference always returns truncated=False (:702)
         infos = {}

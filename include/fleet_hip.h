@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 4
+#define FLEET_ABI_VERSION 5
 
 /* status codes */
 #define FLEET_OK 0
@@ -204,10 +204,16 @@ int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_enviro
 int fleet_create(const FleetParams* p, const FleetTables* t, int device, fleet_handle* out);
 int fleet_destroy(fleet_handle h);
 const char* fleet_last_error(fleet_handle h);  /* h may be NULL: error of the last failed fleet_create */
-int fleet_set_stream(fleet_handle h, void* hip_stream);  /* adopt an external hipStream_t (e.g. torch's) */
+/* Launch on an external hipStream_t from now on (e.g. torch's current stream, so that launches are ordered with the torch ops
+ * around them).  The stream is borrowed: the caller keeps it alive while the handle uses it.  The handle's own stream is
+ * kept; fleet_use_own_stream goes back to it.  Both synchronise the stream in use so far and drop a cached tape graph. */
+int fleet_set_stream(fleet_handle h, void* hip_stream);
+int fleet_use_own_stream(fleet_handle h);
 int fleet_get_stream(fleet_handle h, void** hip_stream); /* the hipStream_t the handle launches on (to order another stream
                                                             against it with events) */
 int fleet_synchronize(fleet_handle h);
+/* non-blocking: FLEET_OK when everything enqueued on the handle's stream has finished, -1 while it has not (hipStreamQuery) */
+int fleet_stream_query(fleet_handle h);
 
 /* Inject episode start rows (parity tests / `set_start_time`): `starts` is HOST [n_episodes,E]; episode k of
  * env e starts at starts[(k % n_episodes)*E + e].  n_episodes = 0 clears the schedule (picker resumes). */
@@ -271,6 +277,9 @@ int fleet_get_dist_factor(fleet_handle h, double* out_host);
  * The step that ends an episode is not logged (:679); with auto-reset the next row is the reset row of the next episode.
  * With real_time = 1 every table row the skipping loop passes gets its row, like in the reference (:677-690). */
 int fleet_log_capacity(fleet_handle h);  /* rows per env; 0 when the log is off */
+/* rows the ring has already overwritten, summed over the envs (sum of max(pos - capacity, 0)): what a caller that wants every
+ * row -- like the reference's unbounded DataLogger -- has lost; size FleetParams.log_capacity so that this stays 0 */
+int fleet_log_dropped(fleet_handle h, int64_t* rows);
 /* copy the ring to HOST buffers (any of them may be NULL); pos [E] = rows written so far per env; synchronous */
 int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs);
 int fleet_log_clear(fleet_handle h);     /* forget all rows (asynchronous on the handle's stream) */

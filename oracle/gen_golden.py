@@ -51,6 +51,10 @@ CONFIGS = {
     # the headline shape itself: 50 EVs per env (the reference needs ~1.6 s per step here, so one env, one 48 h episode)
     "ct50_both_rainflow": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
                                 calculate_degradation=True, deg_emp=False, episode_length=48), 50, 1, 1, "wide"),
+    # the headline shape over an episode boundary: 50 EVs per env, 2 envs x 2 consecutive 48 h episodes -- quirk Q6 (rainflow_length /
+    # fd_cyc / l carried across reset()) at the headline geometry, pinned by the reference itself (about 25 minutes of reference time)
+    "ct50x2_both_rainflow_2ep": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                      calculate_degradation=True, deg_emp=False, episode_length=48), 50, 2, 2, "charge"),
     # remaining observer variants
     "lmd2_building_norm_noaux": (dict(use_case="lmd", building_name="load_lmd.csv", include_building=True,
                                       include_pv=False, normalize_in_env=True, aux=False,

@@ -1,7 +1,8 @@
 """bench.py end to end on the GPU box: the JSON contract at N = 1, and the N = 2 control flow (sharding by rank, barriers,
 max-over-ranks timing, the logging all-gather) with two ranks sharing ONE GPU over gloo -- RCCL refuses two ranks on one
-device, and the pool has no multi-GPU box for the builder; the RCCL path itself is `--backend nccl` (default) and differs
-only in where the gathered tensors live."""
+device, and the pool has no multi-GPU box for the builder.  The RCCL branch itself (`--backend nccl`, the default) runs here
+with ONE rank under the launcher: process-group set-up on the device, barriers, the max-reduce of the region times and the
+all-gather of episode returns all go through RCCL.  `python bench.py --gpus N` without a launcher starts its own ranks."""
 import json
 import os
 import subprocess
@@ -28,6 +29,8 @@ def test_bench_json_contract_single_gpu():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert d["reps"] >= 3 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert "traffic_source" in d["roofline"]
     assert d["n_gpus"] == 1 and d["steps"] == 300 and d["unit"] == "env-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
@@ -52,3 +55,29 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["episodes_gathered"] == 2 * 768  # both ranks' finished episodes arrived through the gather
     assert abs(d["value"] - 2 * 768 * 400 / (d["ms_per_step"] * 400 * 1e-3)) / d["value"] < 1e-9  # whole-job aggregate
     assert "cpu_baseline" not in d and "host_path" not in d  # single-GPU-run items
+
+
+def test_bench_plain_python_starts_its_own_ranks():
+    """What the driver runs for N > 1 when it has no launcher of its own: `python bench.py --gpus 2`.  bench.py starts
+    torch.distributed.run as a child process before anything touches the GPU and relays the single JSON line."""
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "200", "--warmup", "20", "--envs-per-gpu", "512",
+           "--backend", "gloo", "--device-index", "0", "--prime-ms", "50"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["collective_backend"] == "gloo" and d["episodes_gathered"] == 2 * 512
+    assert d["log_gather_ms"] > 0 and d["ms_per_step"] > 0
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """`--backend nccl` (RCCL) under the launcher with world size 1: init_process_group on the device, dist.barrier,
+    all_reduce(MAX) of the region times and the all-gather of episode returns execute on RCCL."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "bench.py", "--gpus", "1", "--steps", "200", "--warmup", "20", "--envs-per-gpu", "512",
+           "--backend", "nccl", "--prime-ms", "50", "--no-cpu-baseline", "--no-host-path"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["episodes_gathered"] == 512

@@ -32,12 +32,12 @@ def _cfg(uc, deg, norm, aux=True, building=True, pv=True, episode_length=24, rea
     }
 
 
-def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=True, seed=0, real_time=False):
+def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=True, seed=0, real_time=False, episode_length=24):
     from fleetrl_amd.batch import FleetBatch
     from oracle.fleet_oracle import OracleBatch
 
     tb = _tables(uc, n_evs)
-    rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv, real_time=real_time))
+    rc = resolve_config(_cfg(uc, deg, norm, aux, building, pv, real_time=real_time, episode_length=episode_length))
     p = make_params(rc, tb, num_envs, seed=seed + 1)
     tf = time_features(tb)
     hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=min(32, max(4, num_envs // 64)))
@@ -70,9 +70,11 @@ def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=
             np.testing.assert_allclose(hip.get("cashflow"), cpu.get("cashflow"), rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(hip.get("ep_return"), cpu.get("ep_return"), rtol=1e-9, atol=1e-8)
             if deg == "rainflow":
+                # (same bounds as the replay of the reference's golden traces, tests/golden_util.py: the cycle stress uses a
+                # hardware float32 logarithm inside x^-0.501, <= 4e-9 relative, see pow_m0501 in fleet_kernels.hip)
                 np.testing.assert_array_equal(hip.get("rf_len"), cpu.get("rf_len"))
-                np.testing.assert_allclose(hip.get("fd_cyc"), cpu.get("fd_cyc"), rtol=1e-6, atol=1e-15)
-                np.testing.assert_allclose(hip.get("sei_l"), cpu.get("sei_l"), rtol=1e-7, atol=1e-15)
+                np.testing.assert_allclose(hip.get("fd_cyc"), cpu.get("fd_cyc"), rtol=1e-8, atol=1e-18)
+                np.testing.assert_allclose(hip.get("sei_l"), cpu.get("sei_l"), rtol=1e-9, atol=1e-18)
     hip.check_errors()
     assert not cpu.get("error_bits").any()
     np.testing.assert_array_equal(hip.get("episodes"), cpu.get("episodes"))
@@ -154,9 +156,10 @@ def test_real_time_event_skipping_matches_oracle(uc, n_evs, num_envs, deg, norm)
 
 
 def test_headline_size_full_batch():
-    """BASELINE.json configs[2] at its FULL size -- 4096 envs x 50 EVs, caretaker fleet, load+pv, rainflow -- HIP against the
-    oracle over more than one 24 h episode (the oracle runs OpenMP over envs; a few seconds on the GPU box's host)."""
-    _compare("ct", 50, 4096, "rainflow", False, steps=200, seed=21)
+    """BASELINE.json configs[2] at its FULL size and as bench.py runs it -- 4096 envs x 50 EVs, caretaker fleet, load+pv,
+    rainflow, 48 h episodes -- HIP against the oracle over two whole episodes and into the third (quirk Q6: rainflow_length /
+    fd_cyc / l carried across resets at the headline geometry and length; the oracle runs OpenMP over envs)."""
+    _compare("ct", 50, 4096, "rainflow", False, steps=2 * 192 + 12, seed=21, episode_length=48)
 
 
 def test_c5_shard_size_full_batch():

@@ -1,0 +1,140 @@
+"""Streaming rainflow under adversarial SOC series, driven through real steps of the C ABI and compared with the CPU
+oracle -- which recounts the whole history with the batch algorithm on every daily row, like the reference
+(oracle/fleet_oracle.c rainflow_cycles / sei_update <-> rainflow_sei_degradation.py:130-195) -- on EVERY step:
+rainflow_length bit-exact, fd_cyc / fd_cal / l / SoH to 1e-9.
+
+The series are made by choosing each action from the EV's current SOC (read back through fleet_get), on a hand-made table
+whose EVs are always plugged in (a constant time_left, i.e. rows that do not follow the run-length rule of the schedule
+records: every row is its own segment and carries its time_left verbatim):
+  * a zigzag whose ranges shrink: nothing ever closes, the stack grows past 64 entries;
+  * a zigzag whose ranges grow: every reversal closes the cycle before it, half cycles at stack size 3;
+  * charging into the target SOC and staying there: plateaus of exactly equal samples (skipped by the reversal
+    extraction), also right before the forced last point of a daily evaluation;
+  * wiggles of a few units in the last place around a level;
+  * full-power alternation, all zeros, and random actions.
+Also here: an episode longer than round 2's 8 188-step limit (90 days) against the oracle."""
+import numpy as np
+import pytest
+
+from fleetrl_amd.config import resolve_config
+from fleetrl_amd.params import make_params, time_features
+from fleetrl_amd.synth import synth_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(episode_length, uc="ct"):
+    return {
+        "data_path": "<synthetic>", "use_case": uc, "building_name": None, "price_name": None, "tariff_name": None,
+        "schedule_name": None, "pv_name": None, "seed": 0, "include_building": True, "include_pv": True,
+        "include_price": True, "time_picker": "random", "max_batt_cap_in_all_use_cases": 60, "init_soh": 1.0,
+        "log_data": False, "deg_emp": False, "calculate_degradation": True, "verbose": 0,
+        "normalize_in_env": False, "aux": True, "ignore_price_reward": False, "ignore_overloading_penalty": False,
+        "ignore_invalid_penalty": False, "ignore_overcharging_penalty": False, "gen_schedule": False,
+        "gen_start_date": None, "gen_end_date": None, "gen_name": None, "gen_n_evs": 1, "spot_markup": None,
+        "spot_mul": None, "feed_in_ded": None, "real_time": False, "episode_length": episode_length, "target_soc": 0.85,
+    }
+
+
+def _always_there_tables(n_evs):
+    tb = synth_tables("ct", n_evs, seed=77)
+    tb.there[:] = 1
+    tb.time_left[:] = 100.0   # never counts down: not a run-length segment, every row carries its own value
+    tb.soc_on_return[:] = 0.5
+    return tb
+
+
+def _check_state(hip, cpu, where):
+    np.testing.assert_array_equal(hip.get("rf_len"), cpu.get("rf_len"), err_msg=f"rainflow_length, {where}")
+    for f in ("fd_cyc", "fd_cal", "sei_l"):
+        np.testing.assert_allclose(hip.get(f), cpu.get(f), rtol=1e-9, atol=1e-18, err_msg=f"{f}, {where}")
+    np.testing.assert_allclose(hip.get("soh"), cpu.get("soh"), rtol=1e-12, err_msg=f"soh, {where}")
+    np.testing.assert_allclose(hip.get("soc_deg"), cpu.get("soc_deg"), rtol=1e-12, atol=1e-15, err_msg=f"soc_deg, {where}")
+
+
+def test_adversarial_soc_series_every_step():
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+
+    N, E = 8, 3
+    tb = _always_there_tables(N)
+    rc = resolve_config(_cfg(48))
+    p = make_params(rc, tb, E, seed=5)
+    tf = time_features(tb)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf)
+    np.testing.assert_array_equal(hip.reset(), cpu.reset())
+    cap, P, dt, eta = float(p.init_battery_cap), min(float(p.obc_max_power), float(p.evse_power)), float(p.dt), float(p.charging_eff)
+    full = P * dt * eta / cap   # SOC gained by one step at full power
+    rng = np.random.default_rng(17)
+    steps = 2 * 192 + 40        # two 48 h episodes and the start of a third (quirk Q6 bookkeeping crosses resets)
+    max_depth = 0
+    for s in range(steps):
+        soc = hip.get("soc")    # [E, N]; identical on both engines (asserted below)
+        a = np.zeros((E, N))
+        for e in range(E):
+            k = s + 7 * e       # the envs run the same patterns out of phase
+            # EV0: shrinking zigzag: the amplitude falls by 0.5 % of a full step per reversal for 190 steps -> nothing closes, the
+            # stack grows to ~190 entries; then it jumps back to a full step, which closes everything at once
+            amp = full * (1.0 - 0.005 * (k % 190))
+            a[e, 0] = (+1 if k % 2 == 0 else -eta) * amp / full
+            # EV1: growing zigzag: every range larger than the one before -> a closure at every reversal
+            amp = full * min(1.0, 0.02 + 0.012 * (k % 80))
+            a[e, 1] = (+1 if k % 2 == 0 else -eta) * amp / full
+            # EV2: into the target and stay (plateau of equal samples), leave it for four steps every 24
+            a[e, 2] = -1.0 if k % 24 in (20, 21, 22, 23) else 1.0
+            # EV3: wiggles of a few ulps: the demanded energy is ~1e-16 of the battery
+            a[e, 3] = (1 if k % 2 else -1) * rng.integers(1, 4) * np.spacing(soc[e, 3]) * cap / (P * dt * eta)
+            # EV4: full-power alternation
+            a[e, 4] = 1.0 if k % 2 else -1.0
+            # EV5: zigzag, then nothing during the ten steps before every daily evaluation row (equal neighbours before the forced point)
+            a[e, 5] = 0.0 if (k % 96) in range(50, 61) else (0.6 if k % 2 else -0.6)
+            # EV6: nothing at all; EV7: random
+            a[e, 7] = rng.uniform(-1, 1)
+        a = np.clip(a, -1, 1)
+        oh, rh, dh, _ = hip.step(a)
+        oc, rcpu, dc, _ = cpu.step(a)
+        np.testing.assert_array_equal(dh, dc, err_msg=f"done, step {s}")
+        np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6, err_msg=f"obs, step {s}")
+        np.testing.assert_allclose(rh, rcpu, rtol=1e-9, atol=1e-9, err_msg=f"reward, step {s}")
+        np.testing.assert_allclose(hip.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-15, err_msg=f"soc, step {s}")
+        _check_state(hip, cpu, f"step {s}")
+        max_depth = max(max_depth, int(cpu.get("rf_len").max()))
+    hip.check_errors()
+    assert not cpu.get("error_bits").any()
+    assert max_depth > 64, max_depth   # the shrinking zigzag really went deep (rainflow_length counts its half cycles)
+    hip.close()
+    cpu.close()
+
+
+def test_ninety_day_episode_rainflow():
+    """`episode_length` is unbounded in the reference (time_config.py:1-24, fleet_environment.py:355); round 2 rejected
+    rainflow episodes beyond 8 188 steps (13-bit stack indices).  A 90-day episode (8 640 steps) against the oracle."""
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+
+    N, E = 6, 4
+    tb = synth_tables("ut", N, seed=31)
+    cfg = _cfg(24 * 90, uc="ut")
+    rc = resolve_config(cfg)
+    p = make_params(rc, tb, E, seed=3, start_range=(0, 96 * 30))   # the episode has to fit into the table year
+    tf = time_features(tb)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf)
+    np.testing.assert_array_equal(hip.reset(), cpu.reset())
+    rng = np.random.default_rng(4)
+    steps = 24 * 4 * 90
+    for s in range(steps):
+        a = rng.uniform(-1, 1, size=(E, N)).astype(np.float32)
+        a[rng.random(a.shape) < 0.15] = 0.0
+        oh, rh, dh, _ = hip.step(a)
+        oc, rcpu, dc, _ = cpu.step(a)
+        np.testing.assert_array_equal(dh, dc, err_msg=f"done, step {s}")
+        if s % 97 == 0 or dh.any():
+            np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6, err_msg=f"obs, step {s}")
+            np.testing.assert_allclose(rh, rcpu, rtol=1e-9, atol=1e-9, err_msg=f"reward, step {s}")
+        if s % 960 == 0 or s == steps - 1:
+            _check_state(hip, cpu, f"step {s}")
+    assert dh.all()   # the episode ended exactly after 8 640 steps
+    _check_state(hip, cpu, "end of the 90-day episode")
+    hip.check_errors()
+    hip.close()
+    cpu.close()

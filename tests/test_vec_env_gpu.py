@@ -187,7 +187,12 @@ def test_data_log_is_written_by_k_step_launches_too():
     small.reset()
     for j in range(g.total):
         small.step(g.actions[:, j])
-    full, tail = venv.env_method("get_log"), small.env_method("get_log")
+    full = venv.env_method("get_log")
+    assert venv.core.batch.log_dropped() == 0
+    # a ring that is too small loses rows the reference's unbounded DataLogger would keep: counted, and get_log() says so
+    assert small.core.batch.log_dropped() == sum(max(len(f) - 50, 0) for f in full) > 0
+    with pytest.warns(RuntimeWarning, match="overwritten"):
+        tail = small.env_method("get_log")
     for e in range(g.E):
         assert len(tail[e]) == 50
         ref = full[e].iloc[-50:].reset_index(drop=True)
