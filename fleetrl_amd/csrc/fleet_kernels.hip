@@ -912,7 +912,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
       const Hot hb = kEarly ? h_pre : d.hot[i];
-      const SegRec rr = kEarly ? run_pre : d.run[i];  // schedule record of row t1
+      // schedule record of row t1: carried with the state (one step per launch) or read from the table (K steps / several EVs
+      // per lane: the time row is in registers there, the table read is not on anybody's critical path, and the carried
+      // record is rewritten once, when the launch ends)
+      const SegRec rr = kEarly ? run_pre : d.seg[(size_t)t1 * N + c];
       const double soh0 = kEarly ? soh_pre : d.soh[i];
       // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
       AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       }
       // the schedule record of the row AFTER next, for the next launch: only when that row starts a new segment of the EV's
       // schedule (a departure, an arrival, ...).  Nothing in this step waits for it except the store at its very end.
-      const bool crosses = (t1 + 1 >= SEG_END(rr.se));
+      const bool crosses = kEarly && (t1 + 1 >= SEG_END(rr.se));
       SegRec nr = rr;
       if (crosses) nr = d.seg[(size_t)t2 * N + c];
       const RowRec tb1 = seg_row(rr, t1, d.dt);
@@ -1194,6 +1197,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     }
   }
 
+  if (!kEarly && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
+    const int rn = r.t + 1 > d.T - 1 ? d.T - 1 : r.t + 1;
+    for (int c = g; c < N; c += G) d.run[(size_t)e * N + c] = d.seg[(size_t)rn * N + c];
+  }
   if (leader && env_ok) {
     EnvRec* er = d.env + e;
     // the head carries the row flags the next launch's state machine needs (struct EnvHead)
