@@ -116,6 +116,36 @@ __device__ __forceinline__ double group_sum_to_last(double v) {
   return v;
 }
 
+// Four per-env sums at once for one env per wavefront (G == 64); the totals are valid in the LAST lane.  The quantities are
+// folded pairwise with the gfx950 lane-swap instructions -- after `v_permlane32_swap` one register holds the lower half's
+// values of a AND b, the other the upper half's, so ONE add folds two quantities from 64 to 32 lanes; `v_permlane16_swap`
+// does the same from 32 to 16 -- which leaves each quantity spread over one 16-lane row; four DPP row shifts finish the rows
+// and three lane reads bring the other rows' totals to the last lane: 27 vector instructions instead of 18 per quantity.
+__device__ __forceinline__ double swap_fold32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);  // lanes 0-31: a folded, 32-63: b folded
+}
+__device__ __forceinline__ double swap_fold16(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);  // rows: x.r0+x.r1, y.r0+y.r1, x.r2+x.r3, y.r2+y.r3
+}
+__device__ __forceinline__ double lane_read(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void wave_sum4_to_last(double& a, double& b, double& c, double& dd) {
+  double z = swap_fold16(swap_fold32(a, b), swap_fold32(c, dd));  // row 0: a, row 1: c, row 2: b, row 3: dd (16 partial sums each)
+  z = dpp_add<0x111, 0xF>(z);
+  z = dpp_add<0x112, 0xF>(z);
+  z = dpp_add<0x114, 0xF>(z);
+  z = dpp_add<0x118, 0xF>(z);  // row totals in lanes 15, 31, 47, 63
+  a = lane_read(z, 15);
+  c = lane_read(z, 31);
+  b = lane_read(z, 47);
+  dd = z;  // the last lane's own row
+}
+
 // Philox4x32-10 start-row sampler; same specification as the oracle's (counter = (global env, episode, 0, 0)).
 __device__ __forceinline__ uint32_t philox_start(unsigned long long seed, uint32_t env, uint32_t episode) {
   uint32_t c0 = env, c1 = episode, c2 = 0, c3 = 0;
@@ -892,36 +922,44 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     RfTop sei_top = {0.0, 0.0};
     bool sei_have_top = false;
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
-    // one EV per lane and one step per launch: the tail of the EV's step (rainflow push, state stores) is deferred until
-    // after the per-env reductions, so that the push's memory round trip has them to hide behind as well
-#ifdef FLEET_RF_LATE
-    constexpr bool kLate = kEarly && !LOG;
+    // Several EVs per lane, one step per launch (N > 64): the lane's NEXT EV's records are requested before the current EV is
+    // worked on (software pipelining of the lane loop) -- otherwise every turn of the loop starts with a memory round trip
+#ifdef FLEET_NO_WIDE_PIPE
+    constexpr bool kPipe = false;
 #else
-    constexpr bool kLate = false;
+    constexpr bool kPipe = WIDE && !MULTI;
 #endif
-    size_t lt_i = 0;
-    int lt_c = 0, lt_tail = 0, lt_sgn = 0;
-    RfReq lt_rq;
-    lt_rq.push = false;
-    double lt_soc = 0.0, lt_soc_deg = 0.0, lt_old_deg = 0.0, lt_soh0 = 0.0;
-    float lt_hl = 0.0f;
-    uint32_t lt_there = 0;
-    bool lt_t090 = false, lt_inplane = false, lt_crosses = false, lt_valid = false;
-    SegRec lt_nr = {0.0, 0u, 0u};
+    Hot hb_n = {0.0, 0.0f, 0u};
+    SegRec rr_n = {0.0, 0u, 0u};
+    double soh_n = 0.0, act_n = 0.0;
+    AuxRec ar_n = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto request_ev = [&](int cn) {
+      const int cc = cn < N ? cn : N - 1;  // past the end: a harmless re-read of the last EV (no exec-mask region)
+      const size_t in = (size_t)e * N + cc;
+      hb_n = d.hot[in];
+      soh_n = d.soh[in];
+      act_n = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + cc] : (double)((const float*)actions)[abase + cc];
+      rr_n = d.seg[(size_t)t1 * N + cc];
+      ar_n = d.aux_tab[(size_t)t1 * N + cc];
+    };
+    if (kPipe) request_ev(g);
     for (int c = g + kz; c < N; c += G) {
       const size_t i = (size_t)e * N + c;
       // all loads of this EV are issued before anything is consumed
-      const Hot hb = kEarly ? h_pre : d.hot[i];
+      const Hot hb = kEarly ? h_pre : (kPipe ? hb_n : d.hot[i]);
       // schedule record of row t1: carried with the state (one step per launch) or read from the table (K steps / several EVs
       // per lane: the time row is in registers there, the table read is not on anybody's critical path, and the carried
       // record is rewritten once, when the launch ends)
-      const SegRec rr = kEarly ? run_pre : d.seg[(size_t)t1 * N + c];
-      const double soh0 = kEarly ? soh_pre : d.soh[i];
+      const SegRec rr = kEarly ? run_pre : (kPipe ? rr_n : d.seg[(size_t)t1 * N + c]);
+      const double soh0 = kEarly ? soh_pre : (kPipe ? soh_n : d.soh[i]);
       // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
       AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifndef FLEET_ABL_NO_AUXLOAD
-      if (write_step_obs || logs) ar = d.aux_tab[(size_t)t1 * N + c];
+      if (kPipe) ar = ar_n;
+      else if (write_step_obs || logs) ar = d.aux_tab[(size_t)t1 * N + c];
 #endif
+      const double act_cur = act_n;
+      if (kPipe) request_ev(c + G);
       // last logged SOC sample: shares the record's float64 field with the SOC (struct Hot); the soc_deg plane only holds
       // it in a combination that does not occur inside the reference's episodes (dependent load, INPLANE)
       const bool inplane = HOT_INPLANE(hb.bits);
@@ -950,6 +988,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         float a32 = a32_pre;
         asm volatile("" : "+v"(a32));
         a = A64 ? a64_pre : (double)a32;
+      } else if (kPipe) {
+        a = act_cur;
       } else {
         a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
       }
@@ -1053,25 +1093,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
-      if (kLate) {  // one EV per lane: the rest of the EV's step runs after the per-env reductions (below)
-        lt_i = i;
-        lt_c = c;
-        lt_rq = rq;
-        lt_tail = tail;
-        lt_sgn = sgn;
-        lt_soc = soc;
-        lt_soc_deg = soc_deg;
-        lt_old_deg = old_deg;
-        lt_hl = hl;
-        lt_there = tb1.there;
-        lt_t090 = t090;
-        lt_inplane = inplane;
-        lt_crosses = crosses;
-        lt_nr = nr;
-        lt_soh0 = soh0;
-        lt_valid = true;
-        break;
-      }
       ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
                            crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
@@ -1092,11 +1113,19 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
 #ifndef FLEET_ABL_NO_REDUCE
-    cash = group_sum_to_last<G>(cash);
-    rew = group_sum_to_last<G>(rew);
-    asum = group_sum_to_last<G>(asum);
+#ifdef FLEET_NO_SWAPFOLD
+    if (false) {
+#else
+    if (G == 64) {
 #endif
-    if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
+      wave_sum4_to_last(cash, rew, asum, penrec);
+    } else {
+      cash = group_sum_to_last<G>(cash);
+      rew = group_sum_to_last<G>(rew);
+      asum = group_sum_to_last<G>(asum);
+      if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
+    }
+#endif
     if (log_on) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
@@ -1130,10 +1159,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
         }
       }
     }
-    if (kLate && lt_valid)
-      ev_finish<DEG, WIDE>(d, lt_i, lt_c, N, env_ok, deg_row, dt_step, lt_rq, lt_tail, lt_sgn, lt_soc, lt_soc_deg, lt_old_deg, lt_hl,
-                           lt_there, lt_t090, lt_inplane, lt_crosses, lt_nr, lt_soh0, 0.0, 0.0, false, 0, err, sei_sample, sei_soh, sei_tail,
-                           sei_top, sei_have_top);
     FLEET_STAMP(7);
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
