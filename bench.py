@@ -312,27 +312,33 @@ def main():
     # R regions are run back to back and the MEDIAN one is reported (`reps`, with the fastest and slowest beside it); inside a
     # region the wait for the device is a spin on hipStreamQuery instead of a blocking synchronize.
     reps = args.reps if args.reps else (31 if args.steps <= 256 else 7)
-    walls, ev_regions = [], []
+    walls = []
     for _ in range(reps):
         barrier()
         t0 = time.perf_counter()
+        run(args.steps)
+        for g in groups:
+            g.batch.spin_wait()
+        barrier()
+        walls.append(time.perf_counter() - t0)
+    # the kernels' own time (roofline): HIP events on the streams the kernels run on, around regions of the same K launches
+    # (kept out of the wall-clock regions: two more operations on each stream per region)
+    ev_regions = []
+    for _ in range(min(reps, 7)):
+        barrier()
         for g in groups:
             g.batch.timer_start()
         run(args.steps)
         for g in groups:
             g.batch.timer_mark()
-        for g in groups:
-            g.batch.spin_wait()
-        barrier()
-        walls.append(time.perf_counter() - t0)
-        ev_regions.append([g.batch.timer_read() for g in groups])  # HIP events on the streams the kernels run on
+        ev_regions.append([g.batch.timer_read() for g in groups])
     w = torch.tensor(walls, device=cdev, dtype=torch.float64)
     if launched:
         dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
     walls = [float(x) for x in w.cpu()]
     order = sorted(range(reps), key=lambda i: walls[i])
-    mid = order[reps // 2]
-    wall, ev_ms = walls[mid], ev_regions[mid]
+    wall = walls[order[reps // 2]]
+    ev_ms = sorted(ev_regions, key=max)[len(ev_regions) // 2]
     # ---- logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1) ------------------
     t1 = time.perf_counter()
     off = 0
@@ -366,8 +372,8 @@ def main():
         g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
         g0.batch.synchronize()
         g0.batch.timer_start()
-        reps = max(1, min(args.steps, 2048) // K)
-        for _ in range(reps):
+        many_reps = max(1, min(args.steps, 2048) // K)
+        for _ in range(many_reps):
             g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
         many_ms = g0.batch.timer_stop()
         if check:
@@ -401,9 +407,9 @@ def main():
                          "kernel_ms_event_pair_per_launch": float(np.mean(per))},
             # K steps per launch: only the last step's observation is part of the result (and written), so the
             # algorithmic bytes per env-step are smaller by the observation row for K-1 of the K steps
-            "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * reps / (many_ms * 1e-3),
+            "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * many_reps / (many_ms * 1e-3),
                           "algorithmic_bytes_per_env_step": g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K,
-                          "GBps": (g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K) * g0.E * K * reps / (many_ms * 1e-3) / 1e9},
+                          "GBps": (g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K) * g0.E * K * many_reps / (many_ms * 1e-3) / 1e9},
             "log_gather_ms": gather_ms, "collective_backend": (args.backend if launched else None),
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
