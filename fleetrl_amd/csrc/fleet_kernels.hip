@@ -65,16 +65,21 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
-// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The
-// single-step kernel needs 97 VGPRs; the multi-step kernel 124-126, i.e. it also runs 4 waves per SIMD although it is only
-// asked for 2 (asking for 3 or 4 makes the register allocator spill a little and is slower).
-// Other FLEET_* macros in this file (FLEET_ABL_EMPTY, FLEET_STAMPS) are diagnostics for tools/ab_build.sh and never defined
-// in the product build.
+// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The single-step
+// kernel needs 97 VGPRs.  The multi-step kernel wants ~150; its wavefronts advance independently and are bound by their own
+// dependent round trips, so what counts is that all of a 4096-env batch's wavefronts are resident at once: it is compiled for
+// four per SIMD (128 VGPRs, a few dozen bytes of spills) -- +21 % env-steps/s over the three its natural register count
+// allows (profiles/r03_experiments/ab_multiwaves.log).  With several EVs per lane it stays at two.
+// Other FLEET_* macros in this file (FLEET_ABL_*, FLEET_PAD_*, FLEET_ST_*, FLEET_NO_*, FLEET_STAMPS) are diagnostics for
+// tools/ab_build.sh and never defined in the product build.
 #ifndef FLEET_SINGLE_WAVES
 #define FLEET_SINGLE_WAVES 4
 #endif
 #ifndef FLEET_MULTI_WAVES
-#define FLEET_MULTI_WAVES 2
+#define FLEET_MULTI_WAVES 4
+#endif
+#ifndef FLEET_MULTI_WIDE_WAVES
+#define FLEET_MULTI_WIDE_WAVES 2
 #endif
 #ifndef FLEET_KBLOCK
 #define FLEET_KBLOCK 256
@@ -388,7 +393,20 @@ struct RfReq {
   double w0, w1;   // stack[tail-3], [tail-4] (before the push)
   bool push;
 };
-__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q) {
+// `early`: the row's header and the entries below the top two were already requested at the start of the EV's step (K steps
+// per launch: the same row lines serve all K steps of the launch from the cache, and a wavefront that advances on its own is
+// bound by its own dependent round trips, which this removes from every step that pushes).
+__device__ __forceinline__ void rf_request(const FleetDev& d, size_t i, int tail, RfReq& q) {
+  const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+  q.acc = *reinterpret_cast<const RfAccHead*>(row);
+  q.top = *reinterpret_cast<const RfTop*>(row + 2);
+  // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
+  const double* w = row + RF_HDR_WORDS + (tail - 4);  // tail >= 1
+  q.w1 = w[0];
+  q.w0 = w[1];
+}
+__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
+                                         bool early = false) {
   q.push = false;
   q.p = old_deg;
   // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes the previous
@@ -402,15 +420,7 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old
 #endif
     sgn = s_next;
   }
-  if (q.push) {
-    const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-    q.acc = *reinterpret_cast<const RfAccHead*>(row);
-    q.top = *reinterpret_cast<const RfTop*>(row + 2);
-    // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
-    const double* w = row + RF_HDR_WORDS + (tail - 4);  // tail >= 1
-    q.w1 = w[0];
-    q.w0 = w[1];
-  }
+  if (q.push && !early) rf_request(d, i, tail, q);
 }
 // `top`: the stack top after the push (only written when a point was pushed)
 __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfReq& q, int& tail, RfTop& top, uint32_t& err) {
@@ -751,7 +761,7 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, in
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
-__global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WAVES) void fleet_step_kernel(
+__global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FLEET_MULTI_WAVES) : FLEET_SINGLE_WAVES) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
     // its lanes' state records and action, E and N for their addresses -- is passed here once more, ahead of the argument
@@ -965,6 +975,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
       if (inplane) old_deg = d.soc_deg[i];
+      RfReq rq;
+      rq.push = false;
+#ifdef FLEET_NO_MULTI_RF_EARLY
+      constexpr bool kRfEarly = false;
+#else
+      constexpr bool kRfEarly = MULTI && DEG == FLEET_DEG_RAINFLOW;
+#endif
+      if (kRfEarly && env_ok) rf_request(d, i, HOT_TAIL(hb.bits), rq);
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -1073,8 +1091,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
       // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
       // stores would cost the multi-step kernel a resident wavefront per SIMD)
       constexpr bool kSplitRf = !MULTI;
-      RfReq rq;
-      rq.push = false;
       if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
@@ -1092,7 +1108,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
+      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
       ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
                            crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
@@ -1222,7 +1238,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? FLEET_MULTI_WAVES : FLEET_SINGLE_WA
     }
   }
 
-  if (!kEarly && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
+  // (only where a single-step launch can follow on the same handle: with more EVs than lanes every kernel reads the table)
+  if (!kEarly && !WIDE && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
     const int rn = r.t + 1 > d.T - 1 ? d.T - 1 : r.t + 1;
     for (int c = g; c < N; c += G) d.run[(size_t)e * N + c] = d.seg[(size_t)rn * N + c];
   }
