@@ -14,21 +14,23 @@
 //
 // Mapping.  One *group* of G lanes owns one env (G = smallest power of two >= min(N,64)); a 64-lane wavefront
 // holds 64/G envs and a 256-thread workgroup 256/G.  Lane g of a group owns EVs g, g+G, ...  Per-env sums
-// (cost, revenue, reward, sum(action*there)) are reduced inside the wavefront with DPP row shifts / row
-// broadcasts -- no LDS round trip, no atomics.  Every lane of a group tracks the per-env scalars (time row,
+// (cashflow, reward, sum(action*there), penalty record) are reduced inside the wavefront -- lane-swap folds of four
+// quantities at once for one env per wavefront, DPP row shifts / row broadcasts otherwise -- no LDS round trip, no atomics.  Every lane of a group tracks the per-env scalars (time row,
 // episode end, sample count) redundantly in registers, so nothing written by one lane is re-read by another
 // inside a launch.  No MFMA: there is no contraction on this path.
 //
 // Schedule columns in run-length form.  What a step needs of the (time row, EV) table -- There, time_left, SOC_on_return of
 // the row it advances to -- travels with the state (`run`, struct SegRec in fleet_device.h): a lane holds the record of row
 // t+1 when the launch starts, so nothing it needs to start its arithmetic depends on the env's time row, and it only touches
-// the table when row t+2 crosses a schedule event of its EV (about 4 % of the EV-steps), for the NEXT launch.  The five
-// auxiliary observation slots are computed from that record in the reference's own float64 operations.
+// the table when row t+2 crosses a schedule event of its EV (about 4 % of the EV-steps), for the NEXT launch.  The row
+// flags the state machine needs travel in the env head; the physics record of the time row and the pre-assembled auxiliary
+// observation slots are requested when the head arrives and consumed late (money terms, observation stores).
 //
 // Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
-// simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (reversal
-// stack in HBM, top two entries cached, slope sign, closed-cycle count, sum of cycle means, stress sum of the
-// closed cycles that fall into the reference's slice) and feeds it ONE sample per step.  On the daily 14:45 row
+// simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in HBM:
+// closed-cycle count, sum of cycle means, the two newest stack entries, stress sum of the closed cycles that fall into the
+// reference's slice, reversal stack; slope sign and stack size in the hot record) and feeds it ONE sample per step; the row
+// is only touched by a step that pushes a reversal point, requested in the middle of the step and consumed at its end.  On the daily 14:45 row
 // the forced last point and the residual half cycles are evaluated on a *virtual* copy of the stack (registers
 // only), which reproduces the reference's full recount, including its cross-episode bookkeeping
 // (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
