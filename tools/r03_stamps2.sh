@@ -3,6 +3,7 @@ cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 mkdir -p gpurun_out/r03
 cp fleetrl_amd/libfleet_hip.so /tmp/keep2.so
+trap "cp /tmp/keep2.so fleetrl_amd/libfleet_hip.so" EXIT
 for v in "$@"; do
   cp ab_variants/$v.so fleetrl_amd/libfleet_hip.so
   echo "==== $v" >> gpurun_out/r03/${TAG}_stamps.log
