@@ -47,6 +47,17 @@ def test_step_many_and_graph_tape_equal_single_steps():
     np.testing.assert_array_equal(obs.cpu().numpy(), o)
     for f in ("soc", "soh", "hours_left", "time_idx", "rf_len", "fd_cyc", "episodes", "ep_return"):
         np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
+    # single steps AFTER a K-step launch: the K-step kernel leaves the carried schedule records and the row flags of the env
+    # head behind for the single-step kernel (which reads no table row for them), across schedule events and an episode end
+    more = rng.uniform(-1, 1, size=(200, a.E, g.N)).astype(np.float32)
+    for k in range(200):
+        oa, ra, da, _ = a.step(more[k])
+        ob, rb, db, _ = b.step(more[k])
+        np.testing.assert_array_equal(ob, oa, err_msg=f"obs, single step {k} after the K-step launch")
+        np.testing.assert_array_equal(rb, ra)
+        np.testing.assert_array_equal(db, da)
+    for f in ("soc", "soh", "hours_left", "time_idx", "rf_len", "fd_cyc", "episodes", "ep_return"):
+        np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
     # the same tape, one launch per step, replayed through a captured hipGraph (tape_len | K not required)
     c.run_tape_dev(K, tape.data_ptr(), 23, obs.data_ptr(), rs.data_ptr(), dn.data_ptr(), use_graph=True)
     c.synchronize()
