@@ -972,6 +972,7 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
         h->error = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
         return FLEET_ERR_HIP;
       }
+      (void)hipGraphUpload(h->graph_exec, h->stream);  // best effort: the first replay does not pay for the upload
       h->graph_tape = tape; h->graph_len = tape_len; h->graph_dtype = act_dtype;
       h->graph_obs = obs; h->graph_reward = reward; h->graph_done = done;
     }
