@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
     ap.add_argument("--deg", default=None, choices=["none", "linear", "rainflow"],
                     help="override the config's degradation model (diagnostics)")
+    ap.add_argument("--split", type=int, default=1,
+                    help="diagnostic: run every fleet type's envs as this many handles (own stream each), whose launches overlap")
     ap.add_argument("--reps", type=int, default=None,
                     help="timed regions of exactly --steps launches each, run back to back; the median region is reported "
                          "(default: 31 for runs of up to 256 steps, else 7)")
@@ -266,6 +268,8 @@ def main():
         spec["deg"] = args.deg
     if args.use_case:
         spec["groups"] = (args.use_case,)
+    if args.split > 1:
+        spec["groups"] = tuple(uc for uc in spec["groups"] for _ in range(args.split))
     E = args.envs_per_gpu or spec["envs"]
     N = args.evs or spec["evs"]
     # a graph replays tape_len launches; a run shorter than that replays a graph of its own length

@@ -116,6 +116,9 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   // the rainflow stack size travels in a 26-bit field of the hot record (fleet_device.h HOT_PACK)
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
     return "rainflow/SEI degradation: episode_steps exceeds 67 million (the packed rainflow stack size is 26 bits wide)";
+  // ... and the kernels address an EV's rainflow row as (its env's rows) + a 32-bit byte offset
+  if (p->deg_mode == FLEET_DEG_RAINFLOW && (uint64_t)p->num_cars * ((uint64_t)p->episode_steps + 24) * 8ull >= (1ull << 32))
+    return "rainflow/SEI degradation: num_cars x episode_steps too large (the rainflow rows of one env exceed 4 GiB)";
   if (p->table_rows >= 0x3FFFFFFF) return "table_rows exceeds 2^30 - 1 (segment ends are 30 bits wide)";
   if (t->finish_row)
     for (int r = 0; r < p->table_rows; ++r) {
@@ -446,6 +449,11 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &d.env, E))) return rc;
   if (p->deg_mode == FLEET_DEG_RAINFLOW) {
     d.rf_row_stride = ((RF_HDR_WORDS + d.stack_cap + 15) / 16) * 16;  // RfHdr + stack, rounded to whole 128-byte lines
+    // the kernels address an EV's row as (the env's rows, a scalar base) + a 32-bit byte offset
+    if ((uint64_t)N * (uint64_t)d.rf_row_stride * 8ull >= (1ull << 32)) {
+      b->error = "num_cars x episode length: the rainflow rows of one env exceed 4 GiB";
+      return FLEET_ERR_INVALID;
+    }
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
     // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
     RfHdr h0;

@@ -238,6 +238,39 @@ __device__ __forceinline__ void st_obs(float*, float) {}
 #else
 __device__ __forceinline__ void st_obs(float* p, float v) { st_pol<FLEET_ST_OBS>(p, v); }
 #endif
+// base + 32-bit byte offset.  The offset is made opaque at every use: its 64-bit zero-extension must be formed in the basic
+// block of the access for the instruction selector to see "uniform base + 32-bit lane offset" (scalar-base addressing); a
+// zero-extension hoisted into an earlier block arrives as an anonymous 64-bit vector value and costs a 64-bit vector add.
+// (in place: the caller's variable is the one register all its uses share)
+template <typename T>
+__device__ __forceinline__ T* at_off(T* base, unsigned& byte_off) {
+  asm volatile("" : "+v"(byte_off));
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ const T* at_off(const T* base, unsigned& byte_off) {
+  asm volatile("" : "+v"(byte_off));
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_obs_at(float* base, unsigned& byte_off, float v) { st_obs(at_off(base, byte_off), v); }
+
+// One EV of one env: the planes [E, N] are addressed as (plane + e * N) + c -- the first part is wave-uniform when a
+// wavefront is one env (G == 64) and lives in scalar registers.
+struct EvIx {
+  size_t eN;   // e * N
+  unsigned c;  // EV of the env
+  __device__ __forceinline__ size_t flat() const { return eN + c; }
+};
+template <typename T>
+__device__ __forceinline__ T* ev_at(T* plane, const EvIx& ix) {
+  unsigned off = ix.c * (unsigned)sizeof(T);
+  return at_off(plane + ix.eN, off);
+}
+// the EV's rainflow row (row stride in float64 words; one env's rows stay below 4 GiB: fleet_create checks)
+__device__ __forceinline__ double* rf_row_of(const FleetDev& d, const EvIx& ix, unsigned word = 0) {
+  unsigned off = (ix.c * (unsigned)d.rf_row_stride + word) * 8u;
+  return at_off(d.rf_rows + ix.eN * (size_t)d.rf_row_stride, off);
+}
 
 // The three schedule columns of one (row, EV), decoded from the record of the row's segment.
 struct RowRec {
@@ -260,16 +293,19 @@ __device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
                                              const RowRec& tb, const AuxRec& ar) {
   const int N = d.N;
-  st_obs(row + c, (float)soc);
-  st_obs(row + N + c, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
+  // one 32-bit lane offset for all seven slots; the slot arrays' bases are wave-uniform when a wavefront is one env (scalar
+  // registers, `global_store ... s[base]` addressing: no 64-bit vector address per slot)
+  unsigned o4 = (unsigned)c * 4u;
+  st_obs_at(row, o4, (float)soc);
+  st_obs_at(row + N, o4, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
-  st_obs(a + c, (float)tb.there);
+  st_obs_at(a, o4, (float)tb.there);
   if (!t090) {
-    st_obs(a + N + c, ar.tgt_th);
-    st_obs(a + 2 * N + c, ar.cl);
-    st_obs(a + 3 * N + c, ar.hn);
-    st_obs(a + 4 * N + c, ar.lax);
+    st_obs_at(a + N, o4, ar.tgt_th);
+    st_obs_at(a + 2 * N, o4, ar.cl);
+    st_obs_at(a + 3 * N, o4, ar.hn);
+    st_obs_at(a + 4 * N, o4, ar.lax);
     return;
   }
   const FleetCold* cd = d.self->cold;
@@ -394,20 +430,22 @@ struct RfReq {
   RfTop top;       // stack[tail-2], stack[tail-1]
   double w0, w1;   // stack[tail-3], [tail-4] (before the push)
   bool push;
+  bool win;        // w0 / w1 were requested (else the pops read the stack words)
 };
 // `early`: the row's header and the entries below the top two were already requested at the start of the EV's step (K steps
 // per launch: the same row lines serve all K steps of the launch from the cache, and a wavefront that advances on its own is
 // bound by its own dependent round trips, which this removes from every step that pushes).
-__device__ __forceinline__ void rf_request(const FleetDev& d, size_t i, int tail, RfReq& q) {
-  const double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+__device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int tail, RfReq& q) {
+  const double* row = rf_row_of(d, i);
   q.acc = *reinterpret_cast<const RfAccHead*>(row);
   q.top = *reinterpret_cast<const RfTop*>(row + 2);
   // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
-  const double* w = row + RF_HDR_WORDS + (tail - 4);  // tail >= 1
+  const double* w = rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 4));  // tail >= 1
   q.w1 = w[0];
   q.w0 = w[1];
+  q.win = true;
 }
-__device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
+__device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
                                          bool early = false) {
   q.push = false;
   q.p = old_deg;
@@ -425,9 +463,11 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, size_t i, double old
   if (q.push && !early) rf_request(d, i, tail, q);
 }
 // `top`: the stack top after the push (only written when a point was pushed)
-__device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfReq& q, int& tail, RfTop& top, uint32_t& err) {
+// `acc_out`: the accumulator head after the push (only written when the push closed a cycle)
+__device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAccHead& acc_out,
+                                          uint32_t& err) {
   if (!q.push) return;
-  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+  double* row = rf_row_of(d, i);
   double* stk = row + RF_HDR_WORDS;
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
@@ -437,14 +477,14 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
   double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
   const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
   if (!closes) {
-    st_pol<FLEET_ST_RF>(stk + (tail - 1), b);  // the displaced top joins the stack words; tail >= 1
+    st_pol<FLEET_ST_RF>(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 1)), b);  // the displaced top joins the stack words; tail >= 1
     tail += 1;
     top.s1 = b;
     top.s2 = p;
     st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
     return;
   }
-  int nwin = tail - 2 > 2 ? 2 : tail - 2;  // entries below the top two that are in registers
+  int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;  // entries below the top two that are in registers
   const double w0 = q.w0, w1 = q.w1;
   tail += 1;
   const int L = q.acc.rf_len;
@@ -482,6 +522,7 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
   out.rf_len = L;
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
+  acc_out = out;
   st_pol<FLEET_ST_RF>(reinterpret_cast<RfAccHead*>(row), out);
   st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
   if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
@@ -492,8 +533,9 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, size_t i, const RfR
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
 // is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
 // `top` / `have_top`: the stack top when this step's push has just written it (registers are newer than the row).
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, double v, int n, int tail, const RfTop& top, bool have_top,
-                                             uint32_t& err, double dt_hours) {
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int tail, const RfTop& top, bool have_top,
+                                             uint32_t& err, double dt_hours, int* new_len = nullptr) {
+  const size_t i = ix.flat();
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
   const double* stk = row + RF_HDR_WORDS;
   // everything this needs from memory is requested up front (one round trip)
@@ -575,6 +617,7 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, size_t i, doub
     out.rf_len = len;
     *reinterpret_cast<RfAccHead*>(row) = out;
     reinterpret_cast<RfHdr*>(row)->csum = 0.0;
+    if (new_len) *new_len = len;
   }
   FLEET_STAMP(13);  // SEI model evaluated
   const double s = sei_soh0 - degradation;
@@ -602,7 +645,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // The hot record of an EV whose soc / soc_deg / hours_left are given (struct Hot in fleet_device.h): the shared float64
 // field, the FROZEN / INPLANE flags, and the soc_deg plane entry in the one case that needs it.  `plane_has` = the
 // plane already holds this soc_deg (the EV was INPLANE before and soc_deg has not changed since).
-__device__ __forceinline__ Hot hot_encode(const FleetDev& d, size_t i, double soc, double soc_deg, float hl, int tail, int sgn,
+__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int sgn,
                                           uint32_t there, bool t090, bool plane_has) {
   Hot h;
   h.hl = hl;
@@ -614,7 +657,7 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, size_t i, double so
       h.x = soc_deg;  // soc == +0.0 is implied
     } else {
       inplane = true;
-      if (!plane_has) d.soc_deg[i] = soc_deg;
+      if (!plane_has) d.soc_deg[i.flat()] = soc_deg;
     }
   }
   h.bits = HOT_PACK(tail, sgn, frozen, inplane, there, t090);
@@ -639,7 +682,8 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
   const int next = start + 1 > d.T - 1 ? d.T - 1 : start + 1;
   for (int c = g; c < N; c += G) {
-    const size_t i = (size_t)e * N + c;
+    const EvIx ix = {(size_t)e * N, (unsigned)c};
+    const size_t i = ix.flat();
     const SegRec s0 = d.seg[(size_t)start * N + c];
     const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
     const RowRec tb = seg_row(s0, start, d.dt);
@@ -653,7 +697,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    d.hot[i] = hot_encode(d, i, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
+    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
     d.run[i] = s1;
     d.soh[i] = soh;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
@@ -718,22 +762,23 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
 // The tail of an EV's step: the rainflow push (second half), the linear model's daily update, the data-log row, and the
 // stores of the state records that changed.
 template <int DEG, bool WIDE>
-__device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
+__device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
                                           int tail, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
                                           bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
                                           size_t lrow, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail, RfTop& sei_top,
-                                          bool& sei_have_top) {
+                                          bool& sei_have_top, RfAccHead& acc_c, RfTop& top_c, bool carry) {
   double soh = soh0;
-  RfTop top = {0.0, 0.0};
-  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, err);
+  RfTop top = top_c;
+  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, acc_c, err);
   const bool pushed = rq.push;
+  if (carry && pushed) top_c = top;
   if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
   if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
     sei_sample = soc_deg;
     sei_soh = soh0;
     sei_tail = tail;
     sei_top = top;
-    sei_have_top = pushed;
+    sei_have_top = pushed || carry;
   }
   if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
     double* lev = d.log_ev + lrow * 4 * N + c;
@@ -747,10 +792,10 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, size_t i, int c, in
     // the whole 16-byte record, always: dense full-line stores.  soc_deg == soc whenever the EV has hours left;
     // otherwise it keeps its previous value, which shares the record's float64 field with an empty slot's soc == 0
 #ifndef FLEET_ABL_NO_HOTSTORE
-    st_rec16(d.hot + i, hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane));
+    st_rec16(ev_at(d.hot, i), hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane));
 #endif
-    if (crosses) st_rec16(d.run + i, nr);  // the next launch advances into another segment of the EV's schedule
-    if (DEG == FLEET_DEG_LINEAR && deg_row) d.soh[i] = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
+    if (crosses) st_rec16(ev_at(d.run, i), nr);  // the next launch advances into another segment of the EV's schedule
+    if (DEG == FLEET_DEG_LINEAR && deg_row) *ev_at(d.soh, i) = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
   }
 }
 
@@ -799,14 +844,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
   if (kEarly) {
     // unconditional, straight-line requests (surplus lanes of the group re-read the env's last EV and drop it): no
     // exec-mask region for the compiler to close with a wait before the env record is even requested
-    const size_t i0 = (size_t)e * N + (g < N ? g : N - 1);
+    const EvIx i0 = {(size_t)e * N, (unsigned)(g < N ? g : N - 1)};
     // in the order the step consumes them (the memory system serves the chip-wide burst of these requests roughly first
     // come, first served, and a wavefront's wait counts its loads in issue order): what the charge arithmetic needs first
-    h_pre = p_hot[i0];
-    soh_pre = p_soh[i0];
-    if (A64) a64_pre = ((const double*)p_actions)[i0];
-    else a32_pre = ((const float*)p_actions)[i0];
-    run_pre = p_run[i0];
+    // (full 64-bit lane addresses here: with scalar bases the four requests leave ~1 % later -- each base is a dependent
+    // chain on the one scalar unit --, profiles/r03_experiments/ab_saddr.log)
+    const size_t f0 = i0.flat();
+    h_pre = p_hot[f0];
+    soh_pre = p_soh[f0];
+    if (A64) a64_pre = ((const double*)p_actions)[f0];
+    else a32_pre = ((const float*)p_actions)[f0];
+    run_pre = p_run[f0];
   }
 
   EnvHead r = p_env[e].h;
@@ -851,6 +899,27 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
   const bool rt = MULTI && (d.real_time != 0);
+  // K steps per launch, one EV per lane: the head of the EV's rainflow row (closed-cycle count, sum of means, rainflow_length,
+  // the two newest stack entries) is read ONCE per launch and carried in registers over the K steps -- a push updates the
+  // registers and stores to the row, nothing re-reads it; the stack words are only read when a closure pops into them
+#ifdef FLEET_NO_RF_CARRY
+  constexpr bool kRfCarry = false;
+#else
+  constexpr bool kRfCarry = MULTI && !WIDE && DEG == FLEET_DEG_RAINFLOW;
+#endif
+  // (Carrying the EV's state record, its state of health and the schedule record the same way was measured and is NOT done:
+  // -14 % K-step rate -- the kernel is at the 128-register limit of four resident wavefronts per SIMD, the six extra live
+  // registers spill, and those loads overlap with other wavefronts' arithmetic anyway;
+  // profiles/r03_experiments/ab_stcarry.log.)
+  RfAccHead acc_c = {0.0, 0, 0};
+  RfTop top_c = {0.0, 0.0};
+  auto carry_load = [&]() {
+    const EvIx i0 = {(size_t)e * N, (unsigned)(g < N ? g : N - 1)};
+    const double* row = rf_row_of(d, i0);
+    acc_c = *reinterpret_cast<const RfAccHead*>(row);
+    top_c = *reinterpret_cast<const RfTop*>(row + 2);
+  };
+  if (kRfCarry) carry_load();
   double last_rew = 0.0;
   bool last_done = false;
   uint32_t head_after = 0;   // single step: FLEET_TFLAG_* of the row after the one the launch advances to
@@ -947,28 +1016,29 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
     AuxRec ar_n = {0.0f, 0.0f, 0.0f, 0.0f};
     auto request_ev = [&](int cn) {
       const int cc = cn < N ? cn : N - 1;  // past the end: a harmless re-read of the last EV (no exec-mask region)
-      const size_t in = (size_t)e * N + cc;
-      hb_n = d.hot[in];
-      soh_n = d.soh[in];
-      act_n = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + cc] : (double)((const float*)actions)[abase + cc];
-      rr_n = d.seg[(size_t)t1 * N + cc];
-      ar_n = d.aux_tab[(size_t)t1 * N + cc];
+      const EvIx in = {(size_t)e * N, (unsigned)cc}, ia = {abase, (unsigned)cc}, it = {(size_t)t1 * N, (unsigned)cc};
+      hb_n = *ev_at(d.hot, in);
+      soh_n = *ev_at(d.soh, in);
+      act_n = (act_mode == FLEET_ACT_F64) ? *ev_at((const double*)actions, ia) : (double)*ev_at((const float*)actions, ia);
+      rr_n = *ev_at(d.seg, it);
+      ar_n = *ev_at(d.aux_tab, it);
     };
     if (kPipe) request_ev(g);
     for (int c = g + kz; c < N; c += G) {
-      const size_t i = (size_t)e * N + c;
+      const EvIx i = {(size_t)e * N, (unsigned)c};
       // all loads of this EV are issued before anything is consumed
-      const Hot hb = kEarly ? h_pre : (kPipe ? hb_n : d.hot[i]);
+      const Hot hb = kEarly ? h_pre : (kPipe ? hb_n : *ev_at(d.hot, i));
       // schedule record of row t1: carried with the state (one step per launch) or read from the table (K steps / several EVs
       // per lane: the time row is in registers there, the table read is not on anybody's critical path, and the carried
       // record is rewritten once, when the launch ends)
-      const SegRec rr = kEarly ? run_pre : (kPipe ? rr_n : d.seg[(size_t)t1 * N + c]);
-      const double soh0 = kEarly ? soh_pre : (kPipe ? soh_n : d.soh[i]);
+      const EvIx it1 = {(size_t)t1 * N, (unsigned)c};  // the table row the step advances to
+      const SegRec rr = kEarly ? run_pre : (kPipe ? rr_n : *ev_at(d.seg, it1));
+      const double soh0 = kEarly ? soh_pre : (kPipe ? soh_n : *ev_at(d.soh, i));
       // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
       AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
 #ifndef FLEET_ABL_NO_AUXLOAD
       if (kPipe) ar = ar_n;
-      else if (write_step_obs || logs) ar = d.aux_tab[(size_t)t1 * N + c];
+      else if (write_step_obs || logs) ar = *ev_at(d.aux_tab, it1);
 #endif
       const double act_cur = act_n;
       if (kPipe) request_ev(c + G);
@@ -976,7 +1046,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       // it in a combination that does not occur inside the reference's episodes (dependent load, INPLANE)
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
-      if (inplane) old_deg = d.soc_deg[i];
+      if (inplane) old_deg = d.soc_deg[i.flat()];
       RfReq rq;
       rq.push = false;
 #ifdef FLEET_NO_MULTI_RF_EARLY
@@ -984,7 +1054,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
 #else
       constexpr bool kRfEarly = MULTI && DEG == FLEET_DEG_RAINFLOW;
 #endif
-      if (kRfEarly && env_ok) rf_request(d, i, HOT_TAIL(hb.bits), rq);
+      rq.win = false;
+      if (kRfCarry) {
+        rq.acc = acc_c;
+        rq.top = top_c;
+      } else if (kRfEarly && env_ok) {
+        rf_request(d, i, HOT_TAIL(hb.bits), rq);
+      }
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -1011,13 +1087,15 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       } else if (kPipe) {
         a = act_cur;
       } else {
-        a = (act_mode == FLEET_ACT_F64) ? ((const double*)actions)[abase + c] : (double)((const float*)actions)[abase + c];
+        const EvIx ia = {abase, (unsigned)c};
+        a = (act_mode == FLEET_ACT_F64) ? *ev_at((const double*)actions, ia) : (double)*ev_at((const float*)actions, ia);
       }
       // the schedule record of the row AFTER next, for the next launch: only when that row starts a new segment of the EV's
       // schedule (a departure, an arrival, ...).  Nothing in this step waits for it except the store at its very end.
       const bool crosses = kEarly && (t1 + 1 >= SEG_END(rr.se));
       SegRec nr = rr;
-      if (crosses) nr = d.seg[(size_t)t2 * N + c];
+      const EvIx it2 = {(size_t)t2 * N, (unsigned)c};
+      if (crosses) nr = *ev_at(d.seg, it2);
       const RowRec tb1 = seg_row(rr, t1, d.dt);
 #ifdef FLEET_PAD_VALU_A  // diagnostic: N dependent-free float64 FMAs right where the charge arithmetic starts
       {
@@ -1112,7 +1190,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
       ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
-                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top);
+                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c, top_c,
+                           kRfCarry);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -1184,16 +1263,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
     // G == 64.
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
       for (int c = g; c < N; c += G) {
-        const size_t i = (size_t)e * N + c;
+        const EvIx ix = {(size_t)e * N, (unsigned)c};
+        const size_t i = ix.flat();
         double deg, soh_new;
         if (!WIDE) {
-          deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step);
+          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
+                             kRfCarry ? &acc_c.rf_len : nullptr);
           soh_new = sei_soh - deg;
         } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
           const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
           const RfTop none = {0.0, 0.0};
-          deg = sei_evaluate(*d.self, i, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
+          deg = sei_evaluate(*d.self, ix, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
           soh_new = d.soh[i] - deg;
         }
         d.soh[i] = soh_new;
@@ -1220,6 +1301,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
         head_reset = true;
         if (env_ok) {
           reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
+          if (kRfCarry) carry_load();  // the reset rewrote the row's head (same lane, same addresses: program order holds)
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;

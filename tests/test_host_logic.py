@@ -187,6 +187,24 @@ def test_create_accepts_long_episodes_in_rainflow_mode():
     validate_supported(resolve_config(cfg))
 
 
+def test_create_rejects_rainflow_rows_beyond_a_32_bit_offset():
+    """The kernels address an EV's rainflow row as (the rows of its env) + a 32-bit byte offset: num_cars x episode length
+    combinations whose rows would exceed 4 GiB per env are refused by name, not silently wrapped."""
+    from fleetrl_amd.params import make_params, time_features
+    from fleetrl_amd.synth import synth_tables
+
+    cfg = dict(_cfg(), use_case="ut", episode_length=24)
+    tb = synth_tables("ut", 16, seed=3)
+    p = make_params(resolve_config(cfg), tb, 2, seed=0)
+    tf = time_features(tb)
+    p.episode_steps = 40_000_000  # 16 EVs x 40 M stack words x 8 B = 5.1 GB per env
+    rc, msg = _create_status(p, tb, tf)
+    assert rc == _capi.ERR_INVALID and "4 GiB" in msg
+    p.episode_steps = 24 * 4 * 365
+    rc, msg = _create_status(p, tb, tf)
+    assert rc != _capi.ERR_INVALID, msg
+
+
 def test_create_range_checks_the_irregular_grid_tables():
     """finish_row / lookahead_row entries index the tables on the host (tail rows) and on the device: out-of-range entries
     are rejected instead of read."""
