@@ -320,3 +320,69 @@ def test_seeded_random_configurations(case):
     hip.check_errors()
     hip.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("n_evs,num_envs", [(50, 70), (130, 21), (8, 45)])
+def test_k_steps_per_launch_match_the_oracle_step_by_step(n_evs, num_envs):
+    """`fleet_step_many_dev` at the geometries of the BASELINE shapes -- one env per wavefront with one EV per lane (N = 50: the
+    kernel that carries the head of each EV's rainflow row in registers over the K steps), several EVs per lane (N = 130) and
+    several envs per wavefront (N = 8) -- against the oracle stepped one row at a time with the same action tape: launches of
+    61 steps over 24 h episodes with auto-reset, i.e. episode ends, in-launch resets and daily degradation rows fall INSIDE
+    launches, and single steps follow the last launch on the same handle."""
+    import torch
+
+    from fleetrl_amd.batch import FleetBatch
+    from oracle.fleet_oracle import OracleBatch
+
+    tb = _tables("ct", n_evs)
+    rc = resolve_config(_cfg("ct", "rainflow", False))
+    p = make_params(rc, tb, num_envs, seed=11)
+    tf = time_features(tb)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf, threads=8)
+    np.testing.assert_array_equal(hip.reset(), cpu.reset())
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    K, launches = 61, 5
+    obs = torch.empty((num_envs, hip.obs_dim), device=dev)
+    rs = torch.empty(num_envs, device=dev, dtype=torch.float64)
+    dc = torch.empty(num_envs, device=dev, dtype=torch.int32)
+
+    def check(where):
+        np.testing.assert_array_equal(hip.get("time_idx"), cpu.get("time_idx"), err_msg=where)
+        np.testing.assert_array_equal(hip.get("episodes"), cpu.get("episodes"), err_msg=where)
+        np.testing.assert_array_equal(hip.get("hours_left"), cpu.get("hours_left"), err_msg=where)
+        np.testing.assert_array_equal(hip.get("rf_len"), cpu.get("rf_len"), err_msg=where)
+        np.testing.assert_allclose(hip.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-12, err_msg=where)
+        np.testing.assert_allclose(hip.get("soh"), cpu.get("soh"), rtol=1e-9, err_msg=where)
+        np.testing.assert_allclose(hip.get("fd_cyc"), cpu.get("fd_cyc"), rtol=1e-8, atol=1e-18, err_msg=where)
+        np.testing.assert_allclose(hip.get("sei_l"), cpu.get("sei_l"), rtol=1e-9, atol=1e-18, err_msg=where)
+        np.testing.assert_allclose(hip.get("ep_return"), cpu.get("ep_return"), rtol=1e-9, atol=1e-8, err_msg=where)
+
+    for l in range(launches):
+        acts = rng.uniform(-1, 1, size=(K, num_envs, n_evs)).astype(np.float32)
+        acts[rng.random(acts.shape) < 0.15] = 0.0
+        tape = torch.from_numpy(acts).to(dev)
+        hip.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rs.data_ptr(), dc.data_ptr())
+        hip.synchronize()
+        want_r, want_d = np.zeros(num_envs), np.zeros(num_envs, dtype=np.int32)
+        for k in range(K):
+            oc, r, d, _t = cpu.step(acts[k])
+            want_r += r
+            want_d += d
+        np.testing.assert_array_equal(dc.cpu().numpy(), want_d, err_msg=f"episode ends, launch {l}")
+        np.testing.assert_allclose(rs.cpu().numpy(), want_r, rtol=1e-9, atol=1e-7, err_msg=f"reward sums, launch {l}")
+        np.testing.assert_allclose(obs.cpu().numpy(), oc, rtol=1e-5, atol=1e-6, err_msg=f"last observation, launch {l}")
+        check(f"after launch {l}")
+    assert hip.get("episodes").min() >= 2  # every env went through in-launch resets
+    for s in range(40):  # the single-step kernel continues from what the K-step kernel left behind
+        a = rng.uniform(-1, 1, size=(num_envs, n_evs)).astype(np.float32)
+        oh, rh, dh, _ = hip.step(a)
+        oc, rcpu, dcpu, _ = cpu.step(a)
+        np.testing.assert_array_equal(dh, dcpu)
+        np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6, err_msg=f"obs, single step {s} after the launches")
+        np.testing.assert_allclose(rh, rcpu, rtol=1e-9, atol=1e-9)
+    check("after the single steps")
+    hip.check_errors()
+    assert not cpu.get("error_bits").any()
+    hip.close()
+    cpu.close()
