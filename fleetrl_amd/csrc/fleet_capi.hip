@@ -113,9 +113,9 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
-  // the rainflow stack size travels in a 26-bit field of the hot record (fleet_device.h HOT_PACK)
+  // the size of the EV's reversal log travels in a 22-bit field of the hot record (fleet_device.h HOT_PACK)
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
-    return "rainflow/SEI degradation: episode_steps exceeds 67 million (the packed rainflow stack size is 26 bits wide)";
+    return "rainflow/SEI degradation: episode_steps exceeds 4.19 million (the packed size of the reversal log is 22 bits wide)";
   // ... and the kernels address an EV's rainflow row as (its env's rows) + a 32-bit byte offset
   if (p->deg_mode == FLEET_DEG_RAINFLOW && (uint64_t)p->num_cars * ((uint64_t)p->episode_steps + 24) * 8ull >= (1ull << 32))
     return "rainflow/SEI degradation: num_cars x episode_steps too large (the rainflow rows of one env exceed 4 GiB)";
@@ -124,7 +124,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     for (int r = 0; r < p->table_rows; ++r) {
       if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
       if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r > FLEET_MAX_STACK_ROWS - 3)
-        return "rainflow/SEI degradation: an episode spans more than 67 million rows (the packed rainflow stack size is 26 bits wide)";
+        return "rainflow/SEI degradation: an episode spans more than 4.19 million rows (the packed size of the reversal log is 22 bits wide)";
     }
   if (t->lookahead_row)
     for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
@@ -308,30 +308,6 @@ void build_seg_rows(const FleetParams& p, const FleetTables& t, std::vector<SegR
   }
 }
 
-// The auxiliary observation slots of every (row, EV), pre-assembled for the configured target SOC (observer_bl_pv.py:85-91
-// and, when normalising, oracle_normalization.py:127-131): float64 in the reference's operation order, stored as the
-// float32 words the reference would emit (`there` itself comes from the schedule record).
-void build_aux_rows(const FleetParams& p, const FleetTables& t, std::vector<AuxRec>& aux) {
-  const size_t TN = (size_t)p.table_rows * p.num_cars;
-  aux.assign(TN, AuxRec{0.0f, 0.0f, 0.0f, 0.0f});
-  if (!p.aux) return;
-  const bool norm = p.normalize != 0;
-  const double hn_den = p.evse_power * p.charging_eff;
-  for (size_t k = 0; k < TN; ++k) {
-    const double th = (double)t.there[k];
-    const double tgt_th = p.target_soc * th;
-    const double cl = tgt_th - t.soc_on_return[k];
-    const double hn = cl * p.batt_cap_nominal / hn_den;
-    double lax = ((double)t.time_left[k] / (hn + 0.001) - 1) * th;
-    lax = lax < 0 ? 0 : (lax > 5 ? 5 : lax);
-    AuxRec& x = aux[k];
-    x.tgt_th = (float)(norm ? tgt_th / p.max_soc : tgt_th);
-    x.cl = (float)(norm ? cl / p.max_soc : cl);
-    x.hn = (float)(norm ? hn / p.max_hours_needed : hn);
-    x.lax = (float)(norm ? lax / p.max_laxity : lax);
-  }
-}
-
 int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
@@ -378,8 +354,11 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.penalty_overload = p->penalty_overloading; d.fully_charged_reward = p->fully_charged_reward;
   d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps;
   d.max_time_left = p->max_time_left;
-  d.batt_cap_nominal = p->batt_cap_nominal;
-  d.hn_denominator = p->evse_power * p->charging_eff;
+  // auxiliary observation slots: divisions by constants become multiplications by the correctly rounded reciprocal
+  d.hn_scale = p->batt_cap_nominal / (p->evse_power * p->charging_eff);
+  d.inv_max_soc = p->normalize ? 1.0 / p->max_soc : 1.0;
+  d.inv_max_hours_needed = p->normalize ? 1.0 / p->max_hours_needed : 1.0;
+  d.inv_max_laxity = p->normalize ? 1.0 / p->max_laxity : 1.0;
 
   FleetCold& cd = b->cold_host;
   cd.min_laxity = p->min_laxity; cd.def_soc = p->def_soc; cd.init_soh = p->init_soh; cd.temperature = p->temperature;
@@ -399,9 +378,6 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     std::vector<SegRec> seg;
     build_seg_rows(*p, *t, seg);
     if ((rc = dev_upload(b, &d.seg, seg.data(), seg.size()))) return rc;
-    std::vector<AuxRec> aux;
-    build_aux_rows(*p, *t, aux);
-    if ((rc = dev_upload(b, &d.aux_tab, aux.data(), aux.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
@@ -454,11 +430,33 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
       b->error = "num_cars x episode length: the rainflow rows of one env exceed 4 GiB";
       return FLEET_ERR_INVALID;
     }
+    // When the pending reversal points are counted (fleet_kernels.hip rf_count).  The count itself is cheap; what a launch pays
+    // for is (a) the lines of the EV's private row every count touches and (b) its slowest wavefront.
+    //  * "daily": on the daily row only, where the reference counts, through the workgroup's one LDS area (64 entries per lane,
+    //    one wavefront at a time).  Fewest lines; a counting wavefront does a whole day's points at once, which is free when
+    //    its workgroup slot is refilled by the next generation of wavefronts, or when a wavefront steps K times anyway.
+    //  * "cadence 8": on every 8th table row as well (phased so that the row before the shipped data's 14:45 row counts),
+    //    a few turns at a time, through a window of the wavefront's own.  For one step per launch on a batch that is a single
+    //    generation of resident wavefronts (<= 4096 of them), where a launch lasts as long as its slowest wavefront.
+    // FLEET_RF_CADENCE (0 = daily; 2, 4, 8) overrides, for experiments: the results do not depend on it.
+    {
+      const long waves = (long)E * ((N + 63) / 64);
+      int cad = (waves <= 4096 && N <= 64) ? 8 : 0;
+      if (const char* ov = getenv("FLEET_RF_CADENCE")) {
+        const int v = atoi(ov);
+        if (v == 0 || v == 2 || v == 4 || v == 8) cad = v;
+      }
+      d.rf_cad_mask = cad ? cad - 1 : 0;
+      d.rf_cad_phase = cad ? (58 & (cad - 1)) : -1;
+      d.rf_win_units = cad ? 9 : 32;
+      d.rf_locked = cad ? 0 : 1;
+    }
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
-    // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
+    // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0; reset() seeds the log
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
     h0.rf_len = 1;
+    h0.sz = 1;
     std::vector<RfHdr> hdrs(EN, h0);
     HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, hdrs.data(), sizeof(RfHdr), sizeof(RfHdr), EN,
                                 hipMemcpyHostToDevice, b->stream));
@@ -474,10 +472,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     HIP_TRY(b, hipMemcpyAsync(d.sei, sei.data(), EN * sizeof(SeiRec), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
-  // device-resident copy of the argument block for the out-of-line rare paths (reset, daily degradation)
   if ((rc = dev_alloc(b, &b->self_dev, 1))) return rc;
   d.self = b->self_dev;
-  HIP_TRY(b, hipMemcpyAsync(b->self_dev, &d, sizeof(FleetDev), hipMemcpyHostToDevice, b->stream));
   // ---- staging for host entry points -------------------------------------------------------------------------------
   const size_t OD = (size_t)E * d.obs_dim;
   if ((rc = dev_alloc(b, (char**)&b->st_actions, EN * 8))) return rc;
@@ -493,6 +489,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     if ((rc = dev_alloc(b, &b->st_small, b->small_bytes))) return rc;
     b->st_reward = reinterpret_cast<double*>(b->st_small);
     b->st_done = reinterpret_cast<uint8_t*>(b->st_small + b->small_off_done);
+    d.err_any = reinterpret_cast<uint32_t*>(b->st_small + b->small_off_count + 4);  // the word beside the episode count
     if ((rc = dev_alloc(b, &b->st_term_compact, OD))) return rc;
     HIP_TRY(b, hipHostMalloc((void**)&b->pin_small, b->small_bytes, hipHostMallocDefault));
     HIP_TRY(b, hipHostMalloc(&b->pin_actions, EN * 8, hipHostMallocDefault));
@@ -501,6 +498,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   if ((rc = dev_alloc(b, &b->st_mask, E))) return rc;
   if ((rc = dev_alloc(b, &b->st_dist, EN))) return rc;
   if ((rc = dev_alloc(b, (char**)&b->st_field, EN * 8))) return rc;
+  // device-resident copy of the (now complete) argument block for the out-of-line rare paths (reset, daily degradation)
+  HIP_TRY(b, hipMemcpyAsync(b->self_dev, &d, sizeof(FleetDev), hipMemcpyHostToDevice, b->stream));
   HIP_TRY(b, hipStreamSynchronize(b->stream));
   return FLEET_OK;
 }

@@ -10,8 +10,9 @@
 //     an EV crosses a schedule event, and then for the row AFTER next -- off the step's critical path;
 //   * everything a group needs per env and step sits in ONE 64-byte record (16-byte head + leader statistics);
 //   * the env-level observation blocks and the physics scalars of a time row sit in contiguous rows;
-//   * rarely touched state (rainflow accumulators + stack, SEI model) sits in per-EV 128-byte-aligned rows / 32-byte
-//     records so an event touches one cache line and the hot path none.
+//   * the SOC history the daily degradation pass needs is an append-only log of reversal points per EV (128-byte-aligned
+//     rows): a step that finds a reversal point STORES it and reads nothing; cycle counting happens where the reference
+//     does it, on the daily row.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,17 +65,6 @@ __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
   return left > 0 ? (float)((double)left * dt) : 0.0f;
 }
 
-// Pre-assembled auxiliary observation slots of (time row t, EV c) for the un-degraded target SOC, 16 B
-// (observer_bl_pv.py:85-91 + oracle_normalization.py:127-131), already normalised when normalize_in_env: the float32 words
-// the reference would emit.  Read by the step for the row it advanced to, off its critical path (only the observation
-// stores consume it); an EV whose target was raised to 0.9 (quirk Q7) computes its slots instead.
-struct AuxRec {
-  float tgt_th;  // target_soc * there
-  float cl;      // charging_left
-  float hn;      // hours_needed
-  float lax;     // laxity
-};
-
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)
 #define FLEET_TFLAG_LUNCH 2u  // 11 < hour < 15               (:538)
 
@@ -88,24 +78,29 @@ struct AuxRec {
 //     of the table, hand-made tables) or a reset that starts from soc == -0.0 -- keeps x = soc and puts soc_deg into the
 //     soc_deg plane: FROZEN | INPLANE (read through a dependent load; it does not occur inside the reference's episodes).
 // Everything else that changes rarely has planes of its own that are only written when it changes: `soh` (daily), the
-// schedule record of the next row `run` (at schedule events), the rainflow stack top `rf_top` (when a reversal is pushed).
+// schedule record of the next row `run` (at schedule events), the reversal log of the rainflow count (one word appended
+// when the SOC slope changes sign).
 struct Hot {
   double x;        // episode.soc and / or episode.soc_deg, see above
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
-  uint32_t bits;   // [25:0] rainflow stack size (the stack always starts at slot 0), [26] INPLANE, [28:27] sign of the last
-                   // SOC slope (0 none, 1 up, 2 down), [29] FROZEN, [30] There at the current time row (carried so the
-                   // step needs no table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
+  uint32_t bits;   // [21:0] entries of the EV's reversal log (counted stack + pending points), [25:22] how many of them are pending
+                   // (appended since the last count; saturates at 15: only "none" is acted on, RfHdr.sz is the authority), [26] INPLANE, [28:27] sign of the last SOC slope (0 none, 1 up, 2 down),
+                   // [29] FROZEN, [30] There at the current time row (carried so the step needs no table read for it),
+                   // [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
-#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFFu))
+#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFu))
+#define HOT_PEND(b) ((int)(((b) >> 22) & 15u))
 #define HOT_INPLANE(b) ((((b) >> 26) & 1u) != 0u)
 #define HOT_SGN(b) ((int)(((b) >> 27) & 3u))
 #define HOT_FROZEN(b) ((((b) >> 29) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define FLEET_MAX_STACK_ROWS 0x3FFFFFF  // 26-bit stack size: 67 million samples per episode
-#define HOT_PACK(tail, sgn, frozen, inplane, there, t090)                                                                 \
-  (((uint32_t)(tail) & 0x3FFFFFFu) | ((inplane) ? 0x4000000u : 0u) | (((uint32_t)(sgn) & 3u) << 27) |                    \
-   ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
+#define FLEET_MAX_STACK_ROWS 0x3FFFFF  // 22-bit log size: 4.19 million samples per episode (119 years of 15-minute steps)
+#define FLEET_MAX_PENDING 15           // 4-bit pending count (saturating)
+#define HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090)                                                            \
+  (((uint32_t)(tail) & 0x3FFFFFu) | (((uint32_t)(pend) & 15u) << 22) | ((inplane) ? 0x4000000u : 0u) |                    \
+   (((uint32_t)(sgn) & 3u) << 27) | ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) |                    \
+   ((t090) ? 0x80000000u : 0u))
 // episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
 #define HOT_SOC(h) ((HOT_FROZEN((h).bits) && !HOT_INPLANE((h).bits)) ? 0.0 : (h).x)
 
@@ -144,34 +139,29 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Rainflow row of (env e, EV c): a 48-byte header followed by the reversal stack, 128-byte aligned, so that everything a
-// push touches -- accumulators, the two newest stack entries, the entries right below them -- sits in ONE cache line for
-// the usual stack depths.  Nothing of it is read by a step that pushes no reversal point (three steps in four): whether
-// a step pushes is decided from the hot record alone (sign of the last slope), and only then is the row requested.
-//   * `s2` is the ONLY copy of the newest stack entry: the stack words hold the entries below it (stack[0 .. tail-2];
-//     `s1` caches the last of them).  A push that closes no cycle therefore writes one stack word (the displaced old
-//     top), and a push that closes a full cycle writes none (the two popped points vanish, the new point stays in s2).
-//   * what every closure reads and writes sits in the first 16 bytes, the stack top in the next 16.
+// Rainflow row of (env e, EV c), 128-byte aligned: a 32-byte header followed by the EV's REVERSAL LOG.
+// The reference keeps every SOC sample of the episode and re-counts the cycles of the whole history on the daily 14:45 row
+// (rainflow.extract_cycles over LogDataDeg.soc_log, rainflow_sei_degradation.py:130-135); between two daily rows nothing of the
+// count is observable.  Three-point counting only ever looks at reversal points, in order, so a step that finds one (strict
+// sign change of the SOC slope, rainflow.reversals) APPENDS it to the log -- one 8-byte store, no load:
+//   log[0 .. sz)      the three-point stack after the last count (the points no closed cycle has consumed)
+//   log[sz .. tail)   reversal points appended since, not yet counted      (tail lives in Hot.bits, sz in the header)
+// The pending points are counted -- pushed through the three-point rule in order, in place: the stack can never be longer than
+// the number of points counted so far -- on the daily row, where the reference counts, and (one step per launch on a batch
+// that is a single generation of wavefronts) on every 8th table row as well, by the whole wavefront at once (the trigger is a
+// property of the env's time row, so a wavefront that is one env either counts or does not), in an LDS area the rows' newest
+// entries are staged into.  The accumulators over the closed cycles (count, sum of means, stress sum of the
+// reference's slice) are folded in the same order whenever the points are counted, so the result does not depend on WHEN.
 struct RfHdr {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
   int32_t nc;       // closed cycles this episode
-  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
-  double s1;        // stack[tail-2]
-  double s2;        // stack[tail-1]
-  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_finish)
-  double pad;
+  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6: reset() keeps it)
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_count)
+  float maxdod;     // largest range among those cycles (the reference's "DoD too large" test, :164-167)
+  int32_t sz;       // counted stack: log[0 .. sz); log[sz .. tail) are the pending points
 };
-struct RfAccHead {  // bytes 0..15 of RfHdr
-  double mean_sum;
-  int32_t nc;
-  int32_t rf_len;
-};
-struct RfTop {  // bytes 16..31 of RfHdr
-  double s1;
-  double s2;
-};
-#define RF_HDR_WORDS 6  // doubles of the header; the stack follows
-static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAccHead) == 16 && sizeof(RfTop) == 16, "RfHdr layout");
+#define RF_HDR_WORDS 4  // doubles of the header; the log follows
+static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS, "RfHdr layout");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc
@@ -213,10 +203,11 @@ struct FleetDev {
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
-  double batt_cap_nominal, hn_denominator;  // auxiliary observation slots (observer_*.py:88): nominal capacity, evse * eta_c
+  // auxiliary observation slots (observer_*.py:85-91, oracle_normalization.py:127-131), computed per lane from the carried
+  // schedule record: hn_scale = nominal capacity / (evse * eta_c), and the normaliser's reciprocals (1.0 when not normalising)
+  double hn_scale, inv_max_soc, inv_max_hours_needed, inv_max_laxity;
   // ---- read-only tables ---------------------------------------------------------------------------------
   const SegRec* seg;          // [T,N] schedule records in run-length form
-  const AuxRec* aux_tab;      // [T,N] pre-assembled auxiliary observation slots (zeros when aux is off)
   const PhysRow* tab_phys;    // [T]
   const uint8_t* tab_flags;   // [T]
   const float* tab_tail;      // [T,tail_stride]
@@ -231,6 +222,8 @@ struct FleetDev {
   double* soc_deg;    // [E,N] (valid where the INPLANE bit is set)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
+  uint32_t* err_any;  // one word: OR of every FLEET_DEVERR_* bit any env has raised (lives in the block the host-pointer step copies
+                      // back with rewards and dones, so a failing step is reported by that very step at no extra cost)
   // device-side data log (FleetParams.log_data; utils/data_logger/data_logger.py:21-68): a ring of `log_cap` rows per env,
   // written by the kernels in every mode (single step, K-step, policy rollout, reset); env e's next row goes to slot
   // log_pos[e] % log_cap.  All nullptr / 0 when log_data is off.
@@ -240,10 +233,13 @@ struct FleetDev {
   double* log_env;    // [log_cap][E][4] reward, cashflow, overload_amount, cum_soc_missing (:659-661)
   double* log_ev;     // [log_cap][E][4][N] action, (dis)charging energy (ev_charger.py:114,174), degradation, soh
   float* log_obs;     // [log_cap][E][obs_dim] the (normalised) observation of the row
-  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (6 doubles) followed by the reversal stack, EV-major
-                      // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators, stack top
-                      // and the entries below it) instead of one line per field / stack level
+  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (4 doubles) followed by the reversal log, EV-major and
+                      // 128-byte aligned
   int rf_row_stride;  // doubles per row (multiple of 16)
+  // rainflow counting rows: table rows r with (r & rf_cad_mask) == rf_cad_phase, and the daily row (rf_cad_phase < 0: the
+  // daily row only); rf_win_units = 16-byte units of a lane's log staged in the LDS: 9 (the wavefront's own window, 18 entries)
+  // or 32 (the workgroup's one area, 64 entries, taken by one wavefront at a time: rf_locked)
+  int rf_cad_mask, rf_cad_phase, rf_win_units, rf_locked;
 };
 
 // launchers implemented in fleet_kernels.hip

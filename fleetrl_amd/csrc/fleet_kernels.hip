@@ -26,14 +26,13 @@
 // flags the state machine needs travel in the env head; the physics record of the time row and the pre-assembled auxiliary
 // observation slots are requested when the head arrives and consumed late (money terms, observation stores).
 //
-// Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
-// simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in HBM:
-// closed-cycle count, sum of cycle means, the two newest stack entries, stress sum of the closed cycles that fall into the
-// reference's slice, reversal stack; slope sign and stack size in the hot record) and feeds it ONE sample per step; the row
-// is only touched by a step that pushes a reversal point, requested in the middle of the step and consumed at its end.  On the daily 14:45 row
-// the forced last point and the residual half cycles are evaluated on a *virtual* copy of the stack (registers
-// only), which reproduces the reference's full recount, including its cross-episode bookkeeping
-// (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
+// Rainflow without a history replay.  The reference keeps every SOC sample and re-runs rainflow over the whole episode
+// history every simulated day.  Three-point counting only looks at reversal points, in order: a step that finds one (the SOC
+// slope changes sign) appends it to the EV's reversal log in HBM -- ONE 8-byte store, nothing is read -- and the daily 14:45
+// pass counts the points appended since the last pass on top of the stack that pass left (rf_count), evaluates the forced
+// last point and the residual half cycles on a *virtual* copy of the stack (registers only) and applies the SEI model, which
+// reproduces the reference's full recount, including its cross-episode bookkeeping (rainflow_length, quirk Q6), at
+// O(new reversal points + stack depth) instead of O(history).
 #include "fleet_device.h"
 
 #ifdef FLEET_STAMPS
@@ -67,26 +66,18 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
-// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The single-step
-// kernel needs 97 VGPRs.  The multi-step kernel wants ~150; its wavefronts advance independently and are bound by their own
-// dependent round trips, so what counts is that all of a 4096-env batch's wavefronts are resident at once: it is compiled for
-// four per SIMD (128 VGPRs, a few dozen bytes of spills) -- +21 % env-steps/s over the three its natural register count
-// allows (profiles/r03_experiments/ab_multiwaves.log).  With several EVs per lane it stays at two.
-// Other FLEET_* macros in this file (FLEET_ABL_*, FLEET_PAD_*, FLEET_ST_*, FLEET_NO_*, FLEET_STAMPS) are diagnostics for
-// tools/ab_build.sh and never defined in the product build.
-#ifndef FLEET_SINGLE_WAVES
-#define FLEET_SINGLE_WAVES 4
-#endif
-#ifndef FLEET_MULTI_WAVES
-#define FLEET_MULTI_WAVES 4
-#endif
-#ifndef FLEET_MULTI_WIDE_WAVES
-#define FLEET_MULTI_WIDE_WAVES 2
-#endif
+// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The multi-step
+// kernel's wavefronts advance independently and are bound by their own dependent round trips, so what counts is that all of a
+// 4096-env batch's wavefronts are resident at once: four per SIMD (128 VGPRs) -- +21 % env-steps/s over three
+// (profiles/r03_experiments/ab_multiwaves.log).  With several EVs per lane it stays at two.
+constexpr int kSingleWaves = 4, kMultiWaves = 4, kMultiWideWaves = 2;
 #ifndef FLEET_KBLOCK
-#define FLEET_KBLOCK 256
+#define FLEET_KBLOCK 256  // (a macro only because the diagnostic stamp code above indexes its buffer with it)
 #endif
-constexpr int kBlock = FLEET_KBLOCK;  // threads per workgroup
+constexpr int kBlock = FLEET_KBLOCK;
+#ifndef FLEET_SKIP_SAME_HOT
+#define FLEET_SKIP_SAME_HOT 1  // (round-4 A/B switch; to be fixed once measured)
+#endif  // threads per workgroup
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront helpers
@@ -194,50 +185,11 @@ __device__ __forceinline__ double overloading_penalty(double rel, double scale) 
 // ---------------------------------------------------------------------------------------------------------
 // observation assembly (observer_*.py + normalization/*.py); layout: DESIGN.md "Observation row"
 // ---------------------------------------------------------------------------------------------------------
-// Store policies (experiments, tools/ab_build.sh): 0 = plain (write-back L2), 1 = nt, 2 = sc1 (write-through)
-#ifndef FLEET_ST_HOT
-#define FLEET_ST_HOT 0
-#endif
-#ifndef FLEET_ST_RF
-#define FLEET_ST_RF 0
-#endif
-#ifndef FLEET_ST_OBS
-#define FLEET_ST_OBS 1  // observation rows are written once and read by nobody on the chip: -1.5 % per launch measured (r03 ab_nt.log)
-#endif
 typedef float fleet_v4f __attribute__((ext_vector_type(4)));
-typedef float fleet_v2f __attribute__((ext_vector_type(2)));
-template <int MODE, typename T>
-__device__ __forceinline__ void st_pol(T* p, const T& v) {
-  static_assert(sizeof(T) == 16 || sizeof(T) == 8 || sizeof(T) == 4, "4-, 8- or 16-byte store");
-  if (MODE == 0) {
-    *p = v;
-  } else if (sizeof(T) == 16) {
-    fleet_v4f w;
-    __builtin_memcpy(&w, &v, 16);
-    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<fleet_v4f*>(p));
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-  } else if (sizeof(T) == 8) {
-    fleet_v2f w;
-    __builtin_memcpy(&w, &v, 8);
-    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<fleet_v2f*>(p));
-    else asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-  } else {
-    float w;
-    __builtin_memcpy(&w, &v, 4);
-    if (MODE == 1) __builtin_nontemporal_store(w, reinterpret_cast<float*>(p));
-    else asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-  }
-}
-template <typename T>
-__device__ __forceinline__ void st_rec16(T* p, const T& v) {
-  static_assert(sizeof(T) == 16, "16-byte record");
-  st_pol<FLEET_ST_HOT>(p, v);
-}
-#ifdef FLEET_ABL_NO_OBS  // diagnostic builds (tools/ab_build.sh): wrong results on purpose
-__device__ __forceinline__ void st_obs(float*, float) {}
-#else
-__device__ __forceinline__ void st_obs(float* p, float v) { st_pol<FLEET_ST_OBS>(p, v); }
-#endif
+// Observation rows are written once and read by nobody on the chip: non-temporal stores (-1.5 % per launch, r03 ab_nt.log).
+// Everything else is stored plain: write-through (`sc1`) and non-temporal state stores were measured on every class of store
+// and lose everywhere (profiles/r03_experiments/ab_stores.log).
+__device__ __forceinline__ void st_obs(float* p, float v) { __builtin_nontemporal_store(v, p); }
 // base + 32-bit byte offset.  The offset is made opaque at every use: its 64-bit zero-extension must be formed in the basic
 // block of the access for the instruction selector to see "uniform base + 32-bit lane offset" (scalar-base addressing); a
 // zero-extension hoisted into an earlier block arrives as an anonymous 64-bit vector value and costs a 64-bit vector add.
@@ -286,12 +238,25 @@ __device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
   return o;
 }
 
+// 1 / x for the auxiliary slots' one division: hardware reciprocal seed (v_rcp_f64, ~26 good bits) + two Newton steps = full
+// float64 accuracy (<= 1 ulp) in five instructions, against ~14 of the IEEE division sequence with its special-case handling.
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the step
-// advanced to (quirk Q10): pre-assembled on the host for the configured target SOC (`ar`, requested by the caller as soon as
-// the row is known and consumed only here), computed in the reference's own float64 operations (observer_bl_pv.py:85-91,
-// oracle_normalization.py:127-131) for an EV whose target has been raised to 0.9 (quirk Q7).
-__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, bool t090,
-                                             const RowRec& tb, const AuxRec& ar) {
+// advanced to (quirk Q10): there | target_soc * there | charging_left | hours_needed | laxity (observer_bl_pv.py:85-91), each
+// divided by the normaliser's constant when normalize_in_env (oracle_normalization.py:127-131).  They are computed per lane
+// from the carried schedule record in float64 and rounded to float32 like the reference's; the two divisions by constants and
+// the normaliser's are multiplications by the correctly rounded reciprocal and `time_left / (hours_needed + 0.001)` uses
+// rcp_newton: <= 2 ulp of float64 before the rounding to float32, i.e. the float32 word is the reference's except when the
+// float64 value lies within 2e-16 relative of a rounding boundary (tests/test_hip_parity.py reports the exact-match
+// fraction; the north-star tolerance is 1e-5).  Round 3 read these four words from a [T, N] table: 16 bytes per EV and step.
+__device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, double tgt,
+                                             const RowRec& tb) {
   const int N = d.N;
   // one 32-bit lane offset for all seven slots; the slot arrays' bases are wave-uniform when a wavefront is one env (scalar
   // registers, `global_store ... s[base]` addressing: no 64-bit vector address per slot)
@@ -300,31 +265,23 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   st_obs_at(row + N, o4, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
-  st_obs_at(a, o4, (float)tb.there);
-  if (!t090) {
-    st_obs_at(a + N, o4, ar.tgt_th);
-    st_obs_at(a + 2 * N, o4, ar.cl);
-    st_obs_at(a + 3 * N, o4, ar.hn);
-    st_obs_at(a + 4 * N, o4, ar.lax);
-    return;
-  }
-  const FleetCold* cd = d.self->cold;
   const double th = (double)tb.there;
-  const double tgt_th = 0.9 * th;
+  const double tgt_th = tgt * th;
   const double cl = tgt_th - tb.sor;
-  const double hn = cl * cd->batt_cap_nominal / cd->hn_denominator;
-  double lax = ((double)tb.tl / (hn + 0.001) - 1.0) * th;
-  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-  if (cd->normalize) {
-    st_obs(a + N + c, (float)(tgt_th / cd->max_soc));
-    st_obs(a + 2 * N + c, (float)(cl / cd->max_soc));
-    st_obs(a + 3 * N + c, (float)(hn / cd->max_hours_needed));
-    st_obs(a + 4 * N + c, (float)(lax / cd->max_laxity));
+  const double hn = cl * d.hn_scale;
+  double lax = ((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th;
+  lax = fmin(fmax(lax, 0.0), 5.0);  // np.clip(., 0, 5)
+  st_obs_at(a, o4, (float)tb.there);
+  if (d.normalize) {
+    st_obs_at(a + N, o4, (float)(tgt_th * d.inv_max_soc));
+    st_obs_at(a + 2 * N, o4, (float)(cl * d.inv_max_soc));
+    st_obs_at(a + 3 * N, o4, (float)(hn * d.inv_max_hours_needed));
+    st_obs_at(a + 4 * N, o4, (float)(lax * d.inv_max_laxity));
   } else {
-    st_obs(a + N + c, (float)tgt_th);
-    st_obs(a + 2 * N + c, (float)cl);
-    st_obs(a + 3 * N + c, (float)hn);
-    st_obs(a + 4 * N + c, (float)lax);
+    st_obs_at(a + N, o4, (float)tgt_th);
+    st_obs_at(a + 2 * N, o4, (float)cl);
+    st_obs_at(a + 3 * N, o4, (float)hn);
+    st_obs_at(a + 4 * N, o4, (float)lax);
   }
 }
 
@@ -414,144 +371,273 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
   return s_dod * s_soc * stress_temp;
 }
 
-// A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
-// three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
-// The stack of the EV always starts at slot 0 (`tail` = its size; when the three-point rule drops the FIRST point -- the
-// stack is exactly [a, b, p] then -- the survivor below the top is rewritten to slot 0, so no head index exists and the size
-// alone describes it).  Its newest entry lives in the row header only (s2; s1 caches the one below), the entries below it in
-// the stack words behind the header (struct RfHdr in fleet_device.h).
-// The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
-// state machine, knows the new sample and therefore whether a reversal point is pushed, and REQUESTS the EV's row (header
-// head, stack top, the two entries below the top two: three 16-byte loads of one cache line); `rf_finish`, after the
-// observation stores and the money terms, consumes it.  A step that pushes nothing -- three in four -- never touches the row.
-struct RfReq {
-  double p;        // the reversal point to push
-  RfAccHead acc;   // requested when a point is pushed
-  RfTop top;       // stack[tail-2], stack[tail-1]
-  double w0, w1;   // stack[tail-3], [tail-4] (before the push)
-  bool push;
-  bool win;        // w0 / w1 were requested (else the pops read the stack words)
-};
-// `early`: the row's header and the entries below the top two were already requested at the start of the EV's step (K steps
-// per launch: the same row lines serve all K steps of the launch from the cache, and a wavefront that advances on its own is
-// bound by its own dependent round trips, which this removes from every step that pushes).
-__device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int tail, RfReq& q) {
-  const double* row = rf_row_of(d, i);
-  q.acc = *reinterpret_cast<const RfAccHead*>(row);
-  q.top = *reinterpret_cast<const RfTop*>(row + 2);
-  // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
-  const double* w = rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 4));  // tail >= 1
-  q.w1 = w[0];
-  q.w0 = w[1];
-  q.win = true;
+// rainflow.reversals fed one sample per step: equal samples are skipped, and a strict sign change of the slope makes the
+// PREVIOUS sample a reversal point.  Returns whether `old_deg` is one; `sgn` (0 none yet, 1 up, 2 down) is updated.
+__device__ __forceinline__ bool rf_reversal(double old_deg, double soc_deg, int& sgn) {
+  const bool moved = (soc_deg != old_deg);
+  const int s_next = (soc_deg > old_deg) ? 1 : 2;
+  const bool rev = moved && (sgn != 0) && (sgn != s_next);
+  sgn = moved ? s_next : sgn;
+  return rev;
 }
-__device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
-                                         bool early = false) {
-  q.push = false;
-  q.p = old_deg;
-  // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes the previous
-  // sample a reversal point
-  if (soc_deg != old_deg) {
-    const int s_next = (soc_deg > old_deg) ? 1 : 2;
-#ifdef FLEET_ABL_NO_PUSH
-    q.push = false;
-#else
-    q.push = (sgn != 0 && sgn != s_next);
-#endif
-    sgn = s_next;
-  }
-  if (q.push && !early) rf_request(d, i, tail, q);
-}
-// `top`: the stack top after the push (only written when a point was pushed)
-// `acc_out`: the accumulator head after the push (only written when the push closed a cycle)
-__device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAccHead& acc_out,
-                                          uint32_t& err) {
-  if (!q.push) return;
-  double* row = rf_row_of(d, i);
-  double* stk = row + RF_HDR_WORDS;
-  if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
+
+// The reversal point `p` joins the EV's log: one store, nothing is read (struct RfHdr in fleet_device.h).
+__device__ __forceinline__ void rf_append(const FleetDev& d, const EvIx& i, double p, int& tail, int& pend, uint32_t& err) {
+  if (tail >= d.stack_cap) {  // cannot happen (points <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
-  const double p = q.p;
-  double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
-  const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
-  if (!closes) {
-    st_pol<FLEET_ST_RF>(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 1)), b);  // the displaced top joins the stack words; tail >= 1
-    tail += 1;
-    top.s1 = b;
-    top.s2 = p;
-    st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
-    return;
-  }
-  int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;  // entries below the top two that are in registers
-  const double w0 = q.w0, w1 = q.w1;
+  *rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail)) = p;
   tail += 1;
-  const int L = q.acc.rf_len;
-  int nc = q.acc.nc;
-  double mean_sum = q.acc.mean_sum, dcsum = 0.0;
-  bool has_csum = false;
-  while (tail >= 3) {
-    const double X = fabs(p - b), Y = fabs(b - a);
-    if (X < Y) break;
-    if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
-      dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
-      has_csum = true;
-    }
-    mean_sum += 0.5 * (a + b);
-    nc += 1;
-    if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
-      stk[0] = b;
-      tail = 2;
-    } else {  // full cycle, drop its two points -> stack = [..., p]: the stack words keep what they have, p lives in s2
-      tail -= 2;
-      if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
-      else b = stk[tail - 2];
-      if (tail >= 3) {
-        if (nwin >= 2) a = w1;                     // stack[tail-3]
-        else a = stk[tail - 3];
-      } else {
-        a = 0.0;
-      }
-      nwin = 0;
-    }
-  }
-  RfAccHead out;
-  out.mean_sum = mean_sum;
-  out.nc = nc;
-  out.rf_len = L;
-  top.s1 = b;  // stack[tail-2]
-  top.s2 = p;  // stack[tail-1]
-  acc_out = out;
-  st_pol<FLEET_ST_RF>(reinterpret_cast<RfAccHead*>(row), out);
-  st_pol<FLEET_ST_RF>(reinterpret_cast<RfTop*>(row + 2), top);
-  if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
+  pend = pend < FLEET_MAX_PENDING ? pend + 1 : pend;
 }
 
-// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
-// `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
-// residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
-// is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
-// `top` / `have_top`: the stack top when this step's push has just written it (registers are newer than the row).
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int tail, const RfTop& top, bool have_top,
-                                             uint32_t& err, double dt_hours, int* new_len = nullptr) {
-  const size_t i = ix.flat();
-  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  const double* stk = row + RF_HDR_WORDS;
-  // everything this needs from memory is requested up front (one round trip)
-  const RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
-  SeiRec sr = d.sei[i];
-  const int L = hd.rf_len;
-  const int nc = hd.nc;
-  const double mean_sum0 = hd.mean_sum, csum0 = hd.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
-  const double st = d.stress_temp;
-#ifdef FLEET_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  FLEET_STAMP(11);  // records arrived
+// ---- counting the pending points ---------------------------------------------------------------------------------------
+// WHEN: on every table row r with (r & 7) == 2 and on the daily row (FLEET_TFLAG_DEG).  The shipped data's daily row is 14:45
+// = row 59 of the day, and 58 & 7 == 2: the row before it is a counting row, so the daily pass itself finds at most the
+// point of its own step pending.  The trigger is a property of the env's time row: for one env per wavefront the whole
+// wavefront either counts or does not, and 7 of 8 step nothing but the append above.  (With the count at push time, round 3,
+// EVERY wavefront had a pushing lane on every step: a dependent round trip to the EV's row and the closure loop on every
+// wavefront's path; with the count on the daily row only, 1 % of the wavefronts carry a 20 k-cycle pass and end the launch
+// 13 us after everybody else -- both measured, profiles/r04_experiments/.)
+// WHERE: in a window of the wavefront's own LDS: the newest kRfWinEntries entries of every lane's log (pending points + the
+// top of the counted stack) are copied there by the memory system (global_load_lds_dwordx4: no registers, all units in
+// flight at once), requested as soon as the lane's hot record -- which holds the log's size -- has arrived, and consumed after
+// the step's own arithmetic: no round trip on the wavefront's path.  Counting walks the log with data-dependent indices, one
+// dependent access per popped point: ~100 cycles from the LDS, a round trip to the L2 from global memory (the L1 does not
+// keep a line its own wavefront has just stored to; 25 us per daily pass measured that way).  Entries below the window -- a
+// cycle closing deeper than the 9+ staged stack entries -- are read from global memory.
+// (the cadence is a launch parameter, FleetDev.rf_cad_mask / rf_cad_phase: WHEN the points are counted does not change any result)
+constexpr int kRfTurns = 4;      // turns of the counting loop a wavefront takes on an ordinary counting row (rf_count_staged)
+constexpr int kRfBacklog = 5;    // ... unless a lane has more points than this pending
+constexpr int kRfWinUnits = 9;     // 16-byte units per lane of a wavefront's own window (18 entries)
+constexpr int kRfAreaUnits = 32;   // ... of the workgroup's one area (64 entries), FleetDev.rf_locked
+constexpr int kRfWaveLdsBytes = kRfWinUnits * 64 * 16;  // unit u of lane r at byte (u * 64 + r) * 16: what global_load_lds produces
+constexpr int kRfLdsBytes = (kBlock / 64) * kRfWaveLdsBytes;
+static_assert(kRfAreaUnits * 64 * 16 <= kRfLdsBytes, "the workgroup's area is carved from the same LDS block as the four windows");
 
+// (LDS pointers carry their address space in the type: a pointer that may be LDS or global -- e.g. the two arms of `ld` merged
+// into one access -- compiles to FLAT instructions, ~1000 cycles per dependent access; measured.)
+typedef __attribute__((address_space(3))) char fleet_lds_char;
+typedef __attribute__((address_space(3))) double fleet_lds_double;
+typedef __attribute__((address_space(3))) fleet_v4f fleet_lds_v4f;
+struct RfWin {
+  fleet_lds_char* col;  // LDS: this lane's column of the wavefront's window (unit u at col + u * 1024)
+  double* lg;           // global: entry 0 of the EV's log
+  int lo;               // first staged entry (even): the window holds log[lo .. lo + cap)
+  int wmin;             // lowest staged entry written (start of the write-back range)
+  int cap;              // entries the window holds (2 * FleetDev.rf_win_units)
+  __device__ __forceinline__ bool staged(int k) const { return (unsigned)(k - lo) < (unsigned)cap; }
+  __device__ __forceinline__ fleet_lds_double* at(int k) const {
+    return reinterpret_cast<fleet_lds_double*>(col + ((k - lo) >> 1) * 1024 + ((k - lo) & 1) * 8);
+  }
+  __device__ __forceinline__ double ld(int k) const {
+    if (__builtin_expect(!staged(k), 0)) return lg[k];  // below the window: a cycle closing deeper than the staged stack
+    return *at(k);
+  }
+  __device__ __forceinline__ void st(int k, double v) {
+    if (__builtin_expect(!staged(k), 0)) {
+      lg[k] = v;
+      return;
+    }
+    *at(k) = v;
+    wmin = k < wmin ? k : wmin;
+  }
+};
+
+// The workgroup's one LDS area (FleetDev.rf_locked) is taken by one wavefront at a time: called by all lanes of a wavefront
+// that count, one of them spins.  A holder never waits for anything but memory, so the lock cannot deadlock.
+__device__ __forceinline__ void rf_area_take(int* lock) {
+  if ((int)(threadIdx.x & 63u) == (int)__ffsll((long long)__ballot(true)) - 1) {
+    while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void rf_area_release(int* lock) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((int)(threadIdx.x & 63u) == (int)__ffsll((long long)__ballot(true)) - 1) atomicExch(lock, 0);
+}
+
+// Request the window and the header of one EV (the lane's).  `tail` = entries of its log.
+__device__ __forceinline__ void rf_stage(const FleetDev& d, const EvIx& ix, fleet_lds_char* lds_wave, int units, int tail, RfWin& w, RfHdr& hd) {
+  double* row = rf_row_of(d, ix);
+  int lo = tail - 2 * units;
+  lo = lo < 0 ? 0 : (lo + 1) & ~1;
+  w.col = lds_wave + (threadIdx.x & 63u) * 16;
+  w.lg = row + RF_HDR_WORDS;
+  w.lo = lo;
+  w.wmin = 0x7FFFFFFF;
+  w.cap = 2 * units;
+  const char* src = reinterpret_cast<const char*>(w.lg + lo);
+  const int nu = (tail - lo + 1) >> 1;
+  // (inline assembly instead of __builtin_amdgcn_global_load_lds: with the builtin the compiler puts an `s_waitcnt vmcnt(0)` in
+  // front of EVERY later LDS read of the kernel -- it cannot see that the copy has completed -- and each of them waits for all
+  // the stores the step has issued meanwhile: 11 k cycles per count measured.  The consumer waits once, explicitly.)
+  const unsigned m0_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds_wave);
+#pragma unroll
+  for (int u = 0; u < kRfAreaUnits; ++u) {
+    if (u >= units) break;  // (wave-uniform)
+    if (u < nu)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0_base + u * 1024), "v"(src + u * 16) : "memory", "m0");
+  }
+  hd = *reinterpret_cast<const RfHdr*>(row);
+}
+
+// The staged pending points log[sz .. tail), then the point of the current step (`has_cur`, not in the log yet), go through
+// the three-point rule (rainflow.extract_cycles, the `while len(points) >= 3` loop) in order, in place, on top of the stack
+// log[0 .. sz).  A closed cycle adds to the episode's cycle count, the sum of cycle means and -- when its index lies in the
+// slice the next evaluation will look at (`iloc[rainflow_length-1 : len-1]`, rainflow_sei_degradation.py:147) -- the stress
+// sum.  Returns the new stack size.
+__device__ __forceinline__ int rf_count_general(RfWin& lg, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur) {
+  const int L = hd.rf_len;
+  int nc = hd.nc;
+  double mean_sum = hd.mean_sum, csum = hd.csum;
+  const int n_pts = (tail - sz) + (has_cur ? 1 : 0);
+  if (n_pts > 0) {
+    double b = lg.ld(sz - 1);  // sz >= 1: reset() seeds the log with the first sample
+    double a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
+    double p_next = (sz < tail) ? lg.ld(sz) : p_cur;
+    int j = sz;
+    for (int q = 0; q < n_pts; ++q, ++j) {
+      const double p = p_next;
+      p_next = (j + 1 < tail) ? lg.ld(j + 1) : p_cur;  // (in flight while this point is counted; no store below reaches j + 1)
+      while (sz >= 2) {  // points [.., a, b, p]
+        const double X = fabs(p - b), Y = fabs(b - a);
+        if (X < Y) break;
+        if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
+          const double rng = fabs(a - b);
+          csum += cycle_stress(rng, 0.5 * (a + b), (sz == 2) ? 0.5 : 1.0, st);
+          hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;  // largest range of the slice ("DoD too large" :164-167 is raised when it is evaluated)
+        }
+        mean_sum += 0.5 * (a + b);
+        nc += 1;
+        if (sz == 2) {  // Y contains the starting point: half cycle, drop the first point -> [b, p]
+          lg.st(0, b);
+          sz = 1;
+          break;
+        }
+        sz -= 2;  // full cycle, drop its two points -> [.., p]
+        b = lg.ld(sz - 1);
+        a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
+      }
+      if (sz != j || j >= tail) lg.st(sz, p);
+      sz += 1;
+      a = b;
+      b = p;
+    }
+  }
+  hd.mean_sum = mean_sum;
+  hd.nc = nc;
+  hd.csum = csum;
+  return sz;
+}
+
+// The same count when the EV's whole log is staged (lo == 0 and the current point still fits: the normal case), as ONE loop
+// whose body has no branches on the common paths: every turn either closes the cycle (a, b) or pushes the point p, chosen per
+// lane with selects, so 64 lanes with 64 different point sequences walk it together (the nested loops of the general form
+// above serialise every lane's path: 11 k cycles per count of eight points measured).  A turn costs ~45 instructions = ~180
+// cycles of the SIMD, whatever the lanes do; a lane needs one turn per point and one per closed cycle.
+//   * the top of the stack lives in registers (b, a); c, d = the two entries below are re-read from the LDS behind every turn:
+//     they are not needed before the turn after next;
+//   * LDS addresses are carried along instead of being rebuilt from indices: log[k] sits at col + (k >> 1) * 1024 + (k & 1) * 8,
+//     so one entry up is `step` = 8 from an even k and 1016 from an odd one (step flips with the parity), two are 1024;
+//   * the half cycle (a closing range that contains the log's very first point) and the stress of a cycle inside the slice of
+//     the next evaluation are rare and take real branches.
+// `turns`: the wavefront stops after that many turns (a launch lasts as long as its slowest wavefront, and the slowest is the one
+// that holds the lane with the longest point sequence of the whole batch) unless a lane's backlog is long; the points that are
+// left stay pending, moved down behind the stack, for the next counting row.
+__device__ __forceinline__ int rf_count_staged(RfWin& w, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur, int turns,
+                                               int& left_out) {
+  const int L = hd.rf_len;
+  int nc = hd.nc;
+  double mean_sum = hd.mean_sum;
+  fleet_lds_char* const col = w.col;
+  auto at = [&](int k) -> fleet_lds_char* { return col + ((k >> 1) << 10) + ((k & 1) << 3); };
+  auto ld = [&](fleet_lds_char* q) -> double { return *reinterpret_cast<const fleet_lds_double*>(q < col ? col : q); };  // (below the
+                                                                          // stack: any staged word, the value is not used)
+  if (has_cur) *reinterpret_cast<fleet_lds_double*>(at(tail)) = p_cur;  // the current step's point joins the staged pending points
+  int left = (tail - sz) + (has_cur ? 1 : 0);                           // points still to be counted
+  fleet_lds_char* As = at(sz);           // where log[sz] goes
+  int step = (sz & 1) ? 1016 : 8;        // As + step = where log[sz + 1] goes
+  fleet_lds_char* Jc = As;               // where the point being counted sits (log[j], j >= sz)
+  int jstep = step;
+  double b = ld(As - 1024 + step), a = ld(As - 1024), c = ld(As - 2048 + step), dd = ld(As - 2048);
+  double p = ld(Jc), p_nx = ld(Jc + jstep);
+  int szmin = sz;
+  while (left > 0 && (turns-- > 0 || left > kRfBacklog)) {
+    const bool closes = (sz >= 2) && !(fabs(p - b) < fabs(b - a));
+    if (__builtin_expect(closes && nc >= L - 1, 0)) {  // only the closed cycles beyond the last evaluation's count carry stress
+      const double rng = fabs(a - b);
+      hd.csum += cycle_stress(rng, 0.5 * (a + b), (sz == 2) ? 0.5 : 1.0, st);
+      hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;
+    }
+    mean_sum = fma(a + b, closes ? 0.5 : 0.0, mean_sum);  // += 0.5 * (a + b): the product is exact, so one rounding either way
+    nc += closes ? 1 : 0;
+    // closes, sz == 2: Y contains the starting point: half cycle, drop the first point -> the stack is [b]; p is pushed next turn
+    // closes, sz > 2 : full cycle, drop its two points -> [.., c, d]; p again next turn
+    // else           : push, log[sz] = p
+    const bool half = closes && (sz == 2);
+    if (!closes || half) *reinterpret_cast<fleet_lds_double*>(half ? col : As) = half ? b : p;
+    As = half ? col + 8 : (closes ? As - 1024 : As + step);
+    step = half ? 1016 : (closes ? step : 1024 - step);
+    sz = half ? 1 : sz + (closes ? -2 : 1);
+    szmin = half ? 0 : (sz < szmin ? sz : szmin);
+    a = closes ? dd : b;
+    b = half ? b : (closes ? c : p);
+    c = ld(As - 2048 + step);  // log[sz - 3]  (behind the store above: the LDS serves a wavefront's accesses in order)
+    dd = ld(As - 2048);        // log[sz - 4]
+    Jc = closes ? Jc : Jc + jstep;
+    jstep = closes ? jstep : 1024 - jstep;
+    left -= closes ? 0 : 1;
+    p = closes ? p : p_nx;
+    p_nx = ld(Jc + jstep);     // the point after (at most one entry past the staged points: inside the window)
+  }
+  if (left > 0) {  // the points from Jc on move down to log[sz ..): still pending, in order
+    fleet_lds_char* dst = As;
+    int dstep = step;
+    for (int i = 0; i < left; ++i) {
+      *reinterpret_cast<fleet_lds_double*>(dst) = ld(Jc);
+      dst += dstep;
+      dstep = 1024 - dstep;
+      Jc += jstep;
+      jstep = 1024 - jstep;
+    }
+  }
+  left_out = left;
+  w.wmin = szmin < w.wmin ? szmin : w.wmin;
+  hd.mean_sum = mean_sum;
+  hd.nc = nc;
+  return sz;
+}
+
+// Returns the counted stack size; `left_out` points stay pending behind it (0 unless `turns` ran out).
+__device__ __forceinline__ int rf_count(RfWin& w, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur, int turns, int& left_out) {
+  if (__builtin_expect(w.lo == 0 && tail < w.cap - 1, 1)) return rf_count_staged(w, hd, st, sz, tail, has_cur, p_cur, turns, left_out);
+  left_out = 0;
+  return rf_count_general(w, hd, st, sz, tail, has_cur, p_cur);
+}
+
+// Header and the rewritten part of the window back to the EV's row (the counted stack is log[0 .. sz)).
+__device__ __forceinline__ void rf_writeback(const RfWin& w, const RfHdr& hd, int sz) {  // sz: entries of the log (stack + still pending)
+  double* row = w.lg - RF_HDR_WORDS;
+  *reinterpret_cast<RfHdr*>(row) = hd;
+  const int u_end = (sz - w.lo + 1) >> 1;  // units holding log[lo .. sz)
+  for (int u = (w.wmin - w.lo) >> 1; u < u_end; ++u)
+    *reinterpret_cast<fleet_v4f*>(w.lg + w.lo + 2 * u) = *reinterpret_cast<const fleet_lds_v4f*>(w.col + u * 1024);
+}
+
+// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212), after the
+// pending points have been counted: `v` = the sample just logged (rainflow.reversals always yields the last sample), `n` =
+// number of logged samples, `sz` = the counted stack log[0 .. sz).
+//   1. the forced last point and the residual half cycles are evaluated on a virtual copy of the stack (vt, vh, registers);
+//      the counted state is not modified by them;
+//   2. the SEI model, when the cycle list has grown beyond rainflow_length (:144).
+__device__ __forceinline__ double rf_evaluate(const RfWin& lg, RfHdr& hd, SeiRec& sr, double st, double v, int n, int sz, uint32_t& err,
+                                            double dt_hours) {
+  const int L = hd.rf_len, nc = hd.nc;
+  double max_dod = (double)hd.maxdod;  // over the closed cycles of the slice (rf_count; rounded to float32: the test is `> 5`)
   int nv = 0;
-  double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
+  double vmean = 0.0, vsum = 0.0, pend = 0.0;
   bool has_pend = false;
   auto emit = [&](double x1, double x2, double count) {
     if (has_pend) vsum += pend;  // the previous cycle is not the last one
@@ -566,9 +652,10 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
     nv += 1;
   };
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
-    int vt = tail, vh = 0;
+    int vt = sz, vh = 0;
     int size = vt - vh + 1;
-    double a = have_top ? top.s1 : hd.s1, b = have_top ? top.s2 : hd.s2;
+    double b = lg.ld(sz - 1);
+    double a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -579,50 +666,45 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
       } else {
         vt -= 2;
         size -= 2;
-        b = stk[vt - 1];
-        a = (size >= 3) ? stk[vt - 2] : 0.0;
+        b = lg.ld(vt - 1);
+        a = (size >= 3) ? lg.ld(vt - 2) : 0.0;
       }
     }
-    // remaining ranges are half cycles: stack[vh..vt) followed by the forced point
-    double prev = (vt - vh >= 2) ? stk[vh] : b;
+    // remaining ranges are half cycles: log[vh .. vt) followed by the forced point
+    double prev = lg.ld(vh);
     for (int j = vh + 1; j < vt; ++j) {
-      const double cur = (j == vt - 1) ? b : stk[j];
+      const double cur = lg.ld(j);
       emit(prev, cur, 0.5);
       prev = cur;
     }
-    emit(b, v, 0.5);
+    emit(prev, v, 0.5);
   }
 
-  FLEET_STAMP(12);  // stack walked, cycle stresses evaluated
+  FLEET_STAMP(12);
   double degradation = 0.0;
-  double sei_l = sei_l0;
+  double sei_l = sr.sei_l;
   const int len = nc + nv;
   if (len > 0 && len > L) {
     if (max_dod > 5.0) err |= FLEET_DEVERR_DOD_RANGE;
     const double battery_age = (double)(n - 1) * dt_hours * 3600.0;  // max(End) is always the last sample's index
-    const double mean_soc_cal = (mean_sum0 + vmean) / (double)len;
-    const double fd_cyc = fd_cyc0 + (csum0 + vsum);
+    const double mean_soc_cal = (hd.mean_sum + vmean) / (double)len;
+    const double fd_cyc = sr.fd_cyc + (hd.csum + vsum);
     const double fd_cal = (4.14E-10 * battery_age) * exp(1.04 * (mean_soc_cal - 0.5)) * st;
     const double fd = fd_cyc + fd_cal;
     const double alpha = 5.75E-2, beta = 121.0;
     sei_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
     if (sei_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
-    degradation = sei_l - sei_l0;
+    degradation = sei_l - sr.sei_l;
     sr.fd_cyc = fd_cyc;
     sr.fd_cal = fd_cal;
     sr.sei_l = sei_l;
-    RfAccHead out;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
-    out.mean_sum = mean_sum0;
-    out.nc = nc;
-    out.rf_len = len;
-    *reinterpret_cast<RfAccHead*>(row) = out;
-    reinterpret_cast<RfHdr*>(row)->csum = 0.0;
-    if (new_len) *new_len = len;
+    hd.rf_len = len;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
+    hd.csum = 0.0;
+    hd.maxdod = 0.0f;
   }
-  FLEET_STAMP(13);  // SEI model evaluated
-  const double s = sei_soh0 - degradation;
+  FLEET_STAMP(13);
+  const double s = sr.sei_soh - degradation;
   sr.sei_soh = s;
-  d.sei[i] = sr;
   if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
 }
@@ -645,7 +727,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // The hot record of an EV whose soc / soc_deg / hours_left are given (struct Hot in fleet_device.h): the shared float64
 // field, the FROZEN / INPLANE flags, and the soc_deg plane entry in the one case that needs it.  `plane_has` = the
 // plane already holds this soc_deg (the EV was INPLANE before and soc_deg has not changed since).
-__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int sgn,
+__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int pend, int sgn,
                                           uint32_t there, bool t090, bool plane_has) {
   Hot h;
   h.hl = hl;
@@ -660,7 +742,7 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
       if (!plane_has) d.soc_deg[i.flat()] = soc_deg;
     }
   }
-  h.bits = HOT_PACK(tail, sgn, frozen, inplane, there, t090);
+  h.bits = HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090);
   return h;
 }
 
@@ -685,7 +767,9 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const EvIx ix = {(size_t)e * N, (unsigned)c};
     const size_t i = ix.flat();
     const SegRec s0 = d.seg[(size_t)start * N + c];
-    const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
+    // the record the first step of the episode advances to (as one 16-byte word: a struct temporary that is only copied through
+    // stays a private-memory object, which the compiler then parks in the LDS)
+    const fleet_v4f s1 = *reinterpret_cast<const fleet_v4f*>(&d.seg[(size_t)next * N + c]);
     const RowRec tb = seg_row(s0, start, d.dt);
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
@@ -697,23 +781,23 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
-    d.run[i] = s1;
+    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, 0, tb.there, t090, false);  // rainflow: the log is [first sample], counted
+    *reinterpret_cast<fleet_v4f*>(&d.run[i]) = s1;
     d.soh[i] = soh;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
-      RfHdr hd = *hp;  // rainflow_length survives
+      double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+      RfHdr hd = *reinterpret_cast<const RfHdr*>(row);  // rainflow_length survives
       hd.mean_sum = 0.0;
-      hd.csum = 0.0;
       hd.nc = 0;
-      hd.s1 = 0.0;
-      hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
-      *hp = hd;
+      hd.csum = 0.0;
+      hd.maxdod = 0.0f;
+      hd.sz = 1;
+      *reinterpret_cast<RfHdr*>(row) = hd;
+      row[RF_HDR_WORDS] = soc_deg;  // the log is [soc_deg]: the first sample is the first reversal point
     }
-    const AuxRec ar = d.aux_tab[(size_t)start * N + c];
-    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, t090, tb, ar);
+    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
     if (log_on) {
-      write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb, ar);
+      write_obs_ev(d, log_obs_row, c, soc, hl, tgt, tb);
       double* lev = d.log_ev + lrow * 4 * N + c;
       lev[0] = 0.0;
       lev[N] = 0.0;
@@ -740,7 +824,10 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     er->ep_len = 0;
     er->penalty_record = 0.0;
     er->start_done = start;  // bit 31 (episode.done) cleared
-    if (r.t_end > d.T - 1) atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
+    if (r.t_end > d.T - 1) {
+      atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
+      atomicOr(d.err_any, FLEET_DEVERR_TABLE_END);
+    }
   }
 }
 
@@ -759,27 +846,33 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
-// The tail of an EV's step: the rainflow push (second half), the linear model's daily update, the data-log row, and the
-// stores of the state records that changed.
-template <int DEG, bool WIDE>
-__device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
-                                          int tail, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
-                                          bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
-                                          size_t lrow, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail, RfTop& sei_top,
-                                          bool& sei_have_top, RfAccHead& acc_c, RfTop& top_c, bool carry) {
+// The tail of an EV's step: the rainflow log (append, or -- on a counting row -- the count of the pending points), the linear
+// model's daily update, the data-log row, and the stores of the state records that changed.
+//   `counts`: the lane's window and header were requested (rf_stage) when its hot record arrived; `sz_out` = the counted stack.
+template <int DEG>
+__device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, bool rev,
+                                          bool counts, RfWin& win, RfHdr& rhd, int tail, int pend, int sgn, double soc, double soc_deg,
+                                          double old_deg, float hl, uint32_t there1, bool t090, bool inplane, bool crosses, const SegRec& nr,
+                                          double soh0, double a, double en, bool logs, size_t lrow, const Hot& h_in, uint32_t& err, int& sz_out) {
   double soh = soh0;
-  RfTop top = top_c;
-  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, acc_c, err);
-  const bool pushed = rq.push;
-  if (carry && pushed) top_c = top;
-  if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
-  if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
-    sei_sample = soc_deg;
-    sei_soh = soh0;
-    sei_tail = tail;
-    sei_top = top;
-    sei_have_top = pushed || carry;
+  if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
+    if (counts) {
+      FLEET_STAMP(14);
+      const bool cur = rev && (tail < d.self->stack_cap);  // (rare path: its scalars come from the device-resident argument block)
+      if (rev && !cur) err |= FLEET_DEVERR_TABLE_END;
+      int left = 0;
+      const int sz_new = rf_count(win, rhd, d.self->stress_temp, rhd.sz, tail, cur, old_deg, deg_row ? 0x7FFFFFFF : kRfTurns, left);
+      rhd.sz = sz_new;
+      tail = sz_new + left;
+      pend = left < FLEET_MAX_PENDING ? left : FLEET_MAX_PENDING;
+      rf_writeback(win, rhd, tail);
+      FLEET_STAMP(15);
+    } else if (rev) {
+      rf_append(d, i, old_deg, tail, pend, err);
+    }
   }
+  sz_out = tail;
+  if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
   if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
     double* lev = d.log_ev + lrow * 4 * N + c;
     lev[0] = a;
@@ -788,13 +881,15 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
     lev[3 * N] = soh;
   }
   FLEET_STAMP(5);
+  const Hot h_out = hot_encode(d, i, soc, soc_deg, hl, tail, pend, sgn, there1, t090, inplane);
   if (env_ok) {
-    // the whole 16-byte record, always: dense full-line stores.  soc_deg == soc whenever the EV has hours left;
-    // otherwise it keeps its previous value, which shares the record's float64 field with an empty slot's soc == 0
-#ifndef FLEET_ABL_NO_HOTSTORE
-    st_rec16(ev_at(d.hot, i), hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane));
-#endif
-    if (crosses) st_rec16(ev_at(d.run, i), nr);  // the next launch advances into another segment of the EV's schedule
+    // soc_deg == soc whenever the EV has hours left; otherwise it keeps its previous value, which shares the record's float64
+    // field with an empty slot's soc == 0.  An EV that is away and stays away leaves its record as it was: no store (what a
+    // launch leaves dirty in the L2 is written back before it ends).
+    const bool same = (__double_as_longlong(h_out.x) == __double_as_longlong(h_in.x)) &&
+                      (__float_as_uint(h_out.hl) == __float_as_uint(h_in.hl)) && (h_out.bits == h_in.bits);
+    if (!FLEET_SKIP_SAME_HOT || !same) *ev_at(d.hot, i) = h_out;
+    if (crosses) *ev_at(d.run, i) = nr;  // the next launch advances into another segment of the EV's schedule
     if (DEG == FLEET_DEG_LINEAR && deg_row) *ev_at(d.soh, i) = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
   }
 }
@@ -808,22 +903,29 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
 template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
-__global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FLEET_MULTI_WAVES) : FLEET_SINGLE_WAVES) void fleet_step_kernel(
+__global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
     // its lanes' state records and action, E and N for their addresses -- is passed here once more, ahead of the argument
     // block, so that those loads do not wait for an argument fetch.
-    const Hot* __restrict__ p_hot, const SegRec* __restrict__ p_run, const double* __restrict__ p_soh,
-    const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* __restrict__ p_env,
+    // (no __restrict__ on the state pointers: the same kernel stores to these arrays through the argument block)
+    const Hot* p_hot, const SegRec* p_run, const double* p_soh, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* p_env,
     FleetDev d, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
-#ifdef FLEET_ABL_EMPTY
-  if (d.E > 0) return;
-#endif
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
+  // LDS window of the rainflow count, one per wavefront (rf_stage / rf_count): no lock, nothing to initialise
+  __shared__ __attribute__((aligned(16))) char rf_lds[DEG == FLEET_DEG_RAINFLOW ? kRfLdsBytes : 16];
+  __shared__ int rf_lock;
+  const bool rf_locked = (DEG == FLEET_DEG_RAINFLOW) && (d.rf_locked != 0);
+  if (rf_locked) {  // the workgroup's one area instead of a window per wavefront
+    if (threadIdx.x == 0) rf_lock = 0;
+    __syncthreads();
+  }
+  fleet_lds_char* const rf_lds_wave =
+      (fleet_lds_char*)rf_lds + ((DEG == FLEET_DEG_RAINFLOW && !rf_locked) ? (threadIdx.x >> 6) * kRfWaveLdsBytes : 0);
   const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -899,27 +1001,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
   const bool rt = MULTI && (d.real_time != 0);
-  // K steps per launch, one EV per lane: the head of the EV's rainflow row (closed-cycle count, sum of means, rainflow_length,
-  // the two newest stack entries) is read ONCE per launch and carried in registers over the K steps -- a push updates the
-  // registers and stores to the row, nothing re-reads it; the stack words are only read when a closure pops into them
-#ifdef FLEET_NO_RF_CARRY
-  constexpr bool kRfCarry = false;
-#else
-  constexpr bool kRfCarry = MULTI && !WIDE && DEG == FLEET_DEG_RAINFLOW;
-#endif
-  // (Carrying the EV's state record, its state of health and the schedule record the same way was measured and is NOT done:
-  // -14 % K-step rate -- the kernel is at the 128-register limit of four resident wavefronts per SIMD, the six extra live
-  // registers spill, and those loads overlap with other wavefronts' arithmetic anyway;
+  // (K steps per launch: carrying the EV's state record, its state of health and the schedule record in registers over the
+  // K steps was measured and is NOT done: -14 % K-step rate -- the kernel is at the 128-register limit of four resident
+  // wavefronts per SIMD and those loads overlap with other wavefronts' arithmetic anyway;
   // profiles/r03_experiments/ab_stcarry.log.)
-  RfAccHead acc_c = {0.0, 0, 0};
-  RfTop top_c = {0.0, 0.0};
-  auto carry_load = [&]() {
-    const EvIx i0 = {(size_t)e * N, (unsigned)(g < N ? g : N - 1)};
-    const double* row = rf_row_of(d, i0);
-    acc_c = *reinterpret_cast<const RfAccHead*>(row);
-    top_c = *reinterpret_cast<const RfTop*>(row + 2);
-  };
-  if (kRfCarry) carry_load();
   double last_rew = 0.0;
   bool last_done = false;
   uint32_t head_after = 0;   // single step: FLEET_TFLAG_* of the row after the one the launch advances to
@@ -955,7 +1040,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     // the few wavefronts with extra work after the step (daily evaluation, episode end + reset) finish last and set the
     // launch's duration: they get issue priority over their SIMD's other wavefronts for the step itself (-3 % per launch)
-    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
+    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && (deg_row || ((t1 & d.rf_cad_mask) == d.rf_cad_phase) && d.rf_cad_mask >= 3)) || is_done))
+      __builtin_amdgcn_s_setprio(3);
     const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
 
     // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
@@ -999,21 +1085,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
     // what the daily SEI pass needs of the lane's EV, carried in registers when a lane owns one EV (no reload round trip for
     // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
     double sei_sample = 0.0, sei_soh = 0.0;
-    int sei_tail = 0;
-    RfTop sei_top = {0.0, 0.0};
-    bool sei_have_top = false;
+    int sei_sz = 0;
+    RfWin sei_win = {nullptr, nullptr, 0, 0, 0};
+    RfHdr sei_hd = {0.0, 0, 0, 0.0, 0.0f, 0};
+    // rainflow: is the row this step advances to a counting row of the env (rf_count)?
+    const bool cnt_step = (DEG == FLEET_DEG_RAINFLOW) && (deg_row || ((t1 & d.rf_cad_mask) == d.rf_cad_phase));
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     // Several EVs per lane, one step per launch (N > 64): the lane's NEXT EV's records are requested before the current EV is
     // worked on (software pipelining of the lane loop) -- otherwise every turn of the loop starts with a memory round trip
-#ifdef FLEET_NO_WIDE_PIPE
-    constexpr bool kPipe = false;
-#else
     constexpr bool kPipe = WIDE && !MULTI;
-#endif
     Hot hb_n = {0.0, 0.0f, 0u};
     SegRec rr_n = {0.0, 0u, 0u};
     double soh_n = 0.0, act_n = 0.0;
-    AuxRec ar_n = {0.0f, 0.0f, 0.0f, 0.0f};
     auto request_ev = [&](int cn) {
       const int cc = cn < N ? cn : N - 1;  // past the end: a harmless re-read of the last EV (no exec-mask region)
       const EvIx in = {(size_t)e * N, (unsigned)cc}, ia = {abase, (unsigned)cc}, it = {(size_t)t1 * N, (unsigned)cc};
@@ -1021,7 +1104,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       soh_n = *ev_at(d.soh, in);
       act_n = (act_mode == FLEET_ACT_F64) ? *ev_at((const double*)actions, ia) : (double)*ev_at((const float*)actions, ia);
       rr_n = *ev_at(d.seg, it);
-      ar_n = *ev_at(d.aux_tab, it);
     };
     if (kPipe) request_ev(g);
     for (int c = g + kz; c < N; c += G) {
@@ -1034,12 +1116,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       const EvIx it1 = {(size_t)t1 * N, (unsigned)c};  // the table row the step advances to
       const SegRec rr = kEarly ? run_pre : (kPipe ? rr_n : *ev_at(d.seg, it1));
       const double soh0 = kEarly ? soh_pre : (kPipe ? soh_n : *ev_at(d.soh, i));
-      // pre-assembled auxiliary observation slots of the row the step advances to: consumed by the observation stores only
-      AuxRec ar = {0.0f, 0.0f, 0.0f, 0.0f};
-#ifndef FLEET_ABL_NO_AUXLOAD
-      if (kPipe) ar = ar_n;
-      else if (write_step_obs || logs) ar = *ev_at(d.aux_tab, it1);
-#endif
       const double act_cur = act_n;
       if (kPipe) request_ev(c + G);
       // last logged SOC sample: shares the record's float64 field with the SOC (struct Hot); the soc_deg plane only holds
@@ -1047,19 +1123,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
       if (inplane) old_deg = d.soc_deg[i.flat()];
-      RfReq rq;
-      rq.push = false;
-#ifdef FLEET_NO_MULTI_RF_EARLY
-      constexpr bool kRfEarly = false;
-#else
-      constexpr bool kRfEarly = MULTI && DEG == FLEET_DEG_RAINFLOW;
-#endif
-      rq.win = false;
-      if (kRfCarry) {
-        rq.acc = acc_c;
-        rq.top = top_c;
-      } else if (kRfEarly && env_ok) {
-        rf_request(d, i, HOT_TAIL(hb.bits), rq);
+      // rainflow, counting row: the EV's window and header are requested now and consumed at the end of its step
+      int tail = HOT_TAIL(hb.bits), pend = HOT_PEND(hb.bits), sgn = HOT_SGN(hb.bits);
+      RfWin win = {nullptr, nullptr, 0, 0, 0};
+      RfHdr rhd = {0.0, 0, 0, 0.0, 0.0f, 0};
+      const bool counts = cnt_step && env_ok && (pend > 0 || deg_row);  // (the daily pass needs the stack in any case)
+      if (counts) {
+        if (rf_locked) rf_area_take(&rf_lock);
+        rf_stage(d, i, rf_lds_wave, d.rf_win_units, tail, win, rhd);
       }
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
@@ -1097,15 +1168,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       const EvIx it2 = {(size_t)t2 * N, (unsigned)c};
       if (crosses) nr = *ev_at(d.seg, it2);
       const RowRec tb1 = seg_row(rr, t1, d.dt);
-#ifdef FLEET_PAD_VALU_A  // diagnostic: N dependent-free float64 FMAs right where the charge arithmetic starts
-      {
-        double p0 = hb.x, p1 = soh0, p2 = a, p3 = hb.x + 1.0;
-#pragma unroll
-        for (int z = 0; z < FLEET_PAD_VALU_A / 4; ++z)
-          asm volatile("v_fma_f64 %0, %0, %0, %1\n v_fma_f64 %1, %1, %1, %2\n v_fma_f64 %2, %2, %2, %3\n v_fma_f64 %3, %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
-        if (p0 + p1 + p2 + p3 == 1.2345e-300) err |= 1u << 30;
-      }
-#endif
       const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
       double soc = HOT_SOC(hb);
       float hl = hb.hl;
@@ -1145,11 +1207,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
         const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
         const double missing = target - soc;
-#ifdef FLEET_ABL_NO_DEPPEN
-        if (false) {
-#else
         if (missing > d.eps) {
-#endif
           const double pen = soc_violation_penalty(missing);
           rew += pen;
           penrec += pen;  // episode.penalty_record (:549,566,584)
@@ -1165,18 +1223,18 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       }
       if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
-      // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
-      // here and consumed after the observation stores and the money terms
-      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
-      // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
-      // stores would cost the multi-step kernel a resident wavefront per SIMD)
-      constexpr bool kSplitRf = !MULTI;
-      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
+      // ---- SOC log (:655): one sample per step; whether the previous sample was a reversal point of the rainflow count
+      const bool rev = (DEG == FLEET_DEG_RAINFLOW) && rf_reversal(old_deg, soc_deg, sgn);
 
       FLEET_STAMP(3);
+      // (counting row: the LDS copy requested when the hot record arrived is waited for HERE, while nothing but loads is
+      // outstanding -- behind the observation stores the same wait would also wait for every one of them to be acknowledged; the
+      // copy is not a register load the compiler tracks)
+      if (DEG == FLEET_DEG_RAINFLOW && cnt_step) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
-      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, t090, tb1, ar);
-      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, t090, tb1, ar);
+      const double tgt_obs = t090 ? 0.9 : d.target_soc;  // the target the observer sees: after this step's sticky update
+      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, tgt_obs, tb1);
+      if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, tgt_obs, tb1);
 
       // ---- money terms of EvCharger.charge: the only consumers of the time row's physics record, which was requested when
       // the env head arrived and has had the charge arithmetic, the state machine and the observation stores to get here
@@ -1188,33 +1246,26 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
-      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
-                           crosses, nr, soh0, a, en, logs, lrow, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c, top_c,
-                           kRfCarry);
+      int sz_out;
+      ev_finish<DEG>(d, i, c, N, env_ok, deg_row, dt_step, rev, counts, win, rhd, tail, pend, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090,
+                     inplane, crosses, nr, soh0, a, en, logs, lrow, hb, err, sz_out);
+      if (WIDE && counts && rf_locked) rf_area_release(&rf_lock);  // (several EVs per lane: the daily pass below stages again)
+      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {  // what the daily pass needs of the lane's EV stays in registers (and in the LDS)
+        sei_sample = soc_deg;
+        sei_soh = soh0;
+        sei_sz = sz_out;
+        sei_win = win;
+        sei_hd = rhd;
+      }
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
     if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
-#ifdef FLEET_PAD_VALU_B  // diagnostic: the same after the EV body, before the reductions
-    {
-      double p0 = cash, p1 = rew, p2 = asum, p3 = cash + 1.0;
-#pragma unroll
-      for (int z = 0; z < FLEET_PAD_VALU_B / 4; ++z)
-        asm volatile("v_fma_f64 %0, %0, %0, %1\n v_fma_f64 %1, %1, %1, %2\n v_fma_f64 %2, %2, %2, %3\n v_fma_f64 %3, %3, %3, %0" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
-      if (p0 + p1 + p2 + p3 == 1.2345e-300) err |= 1u << 30;
-    }
-#endif
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
-#ifndef FLEET_ABL_NO_REDUCE
-#ifdef FLEET_NO_SWAPFOLD
-    if (false) {
-#else
     if (G == 64) {
-#endif
       wave_sum4_to_last(cash, rew, asum, penrec);
     } else {
       cash = group_sum_to_last<G>(cash);
@@ -1222,7 +1273,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       asum = group_sum_to_last<G>(asum);
       if (__any(penrec != 0.0)) penrec = group_sum_to_last<G>(penrec);  // wave-uniform branch; rare
     }
-#endif
     if (log_on) miss_sum = group_sum_to_last<G>(miss_sum);  // kernel-argument-uniform branch (log_data only)
     r.t = t1;
     if (leader) {
@@ -1260,23 +1310,29 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers.  One step in 96, and wave-uniform for
-    // G == 64.
+    // G == 64.  The pending points were counted with the step (ev_finish); the counted stack is still in the wavefront's LDS
+    // window when a lane owns one EV.
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
       for (int c = g; c < N; c += G) {
         const EvIx ix = {(size_t)e * N, (unsigned)c};
         const size_t i = ix.flat();
-        double deg, soh_new;
-        if (!WIDE) {
-          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
-                             kRfCarry ? &acc_c.rf_len : nullptr);
-          soh_new = sei_soh - deg;
-        } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
+        double soh_new = sei_soh;
+        if (WIDE) {  // several EVs per lane: re-read the few words from the records this lane has just stored, stage again
           const Hot hb = d.hot[i];
-          const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
-          const RfTop none = {0.0, 0.0};
-          deg = sei_evaluate(*d.self, ix, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
-          soh_new = d.soh[i] - deg;
+          sei_sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
+          sei_sz = HOT_TAIL(hb.bits);
+          soh_new = d.soh[i];
+          if (rf_locked) rf_area_take(&rf_lock);
+          rf_stage(*d.self, ix, rf_lds_wave, d.rf_win_units, sei_sz, sei_win, sei_hd);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        SeiRec sr = d.sei[i];
+        FLEET_STAMP(11);
+        const double deg = rf_evaluate(sei_win, sei_hd, sr, d.self->stress_temp, sei_sample, r.nsamp, sei_sz, err, dt_step);
+        *reinterpret_cast<RfHdr*>(sei_win.lg - RF_HDR_WORDS) = sei_hd;
+        if (rf_locked) rf_area_release(&rf_lock);
+        d.sei[i] = sr;
+        soh_new -= deg;
         d.soh[i] = soh_new;
         if (logs) {
           double* lev = d.log_ev + lrow * 4 * N + c;
@@ -1301,7 +1357,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
         head_reset = true;
         if (env_ok) {
           reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
-          if (kRfCarry) carry_load();  // the reset rewrote the row's head (same lane, same addresses: program order holds)
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;
@@ -1345,7 +1400,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? FLEET_MULTI_WIDE_WAVES : FL
       if (act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
   }
-  if (err && env_ok) atomicOr(&d.env[e].err, err);
+  if (err && env_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
+    atomicOr(&d.env[e].err, err);
+    atomicOr(d.err_any, err);
+  }
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
 }
@@ -1452,14 +1510,21 @@ int group_size(int N) {
 }
 
 template <int G, int DEG>
-hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
+hipError_t launch_step_gd(const FleetDev& d_in, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
+  FleetDev d = d_in;
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
+  if (!single) {  // a wavefront that steps K times (or skips rows) counts its reversal points on the daily row only (fleet_create)
+    d.rf_cad_mask = 0;
+    d.rf_cad_phase = -1;
+    d.rf_win_units = kRfAreaUnits;
+    d.rf_locked = 1;
+  }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,

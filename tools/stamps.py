@@ -28,8 +28,14 @@ obs = torch.empty((E, b.obs_dim), device=dev)
 rew = torch.empty(E, device=dev, dtype=torch.float64)
 done = torch.empty(E, device=dev, dtype=torch.uint8)
 b.reset_dev(obs.data_ptr())
-b.run_tape_dev(int(os.environ.get("STEPS", 300)), tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=False)  # STEPS=20000: the steady state bench.py measures
+import time as _time
+_n = int(os.environ.get("STEPS", 300))
+b.run_tape_dev(_n - 2000 if _n > 4000 else 0, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=False)  # STEPS=20000: the steady state bench.py measures
 b.synchronize()
+_t0 = _time.perf_counter()
+b.run_tape_dev(2000 if _n > 4000 else _n, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=False)
+b.synchronize()
+print("launch period (eager, stamped build): %.2f us" % ((_time.perf_counter() - _t0) * 1e6 / (2000 if _n > 4000 else _n)))
 lib = _capi.load_library()
 buf = np.zeros(4096 * 16, dtype=np.uint64)
 lib.fleet_debug_read_stamps.argtypes = [C.c_void_p]
@@ -38,7 +44,7 @@ s = buf.reshape(4096, 16)[: min(E, 4096), :9].astype(np.int64)  # one row per wa
 valid = (s > 0).all(axis=1)
 s = s[valid]
 names = ["entry->env head ready", "stage-2 issue + hot loads ready", "charge + state machine", "observation stores",
-         "rainflow update", "state stores", "reductions + leader", "SEI pass / reset", ]
+         "money terms", "log append + state stores", "reductions + leader", "SEI pass / reset", ]
 d = np.diff(s, axis=1)
 print("cycles per segment, median over the wavefronts (last step of the run):")
 for k, n in enumerate(names):
@@ -51,26 +57,20 @@ for name, sel in (("ordinary", ~long), ("long", long)):
     if sel.any():
         print(f"  {name:9s} last segment median {np.median(d[sel, 7]):8.0f}  p90 {np.percentile(d[sel, 7], 90):8.0f}   total median "
               f"{np.median(tot[sel]):8.0f}  p90 {np.percentile(tot[sel], 90):8.0f}")
-# inside the daily evaluation (stamps 11..13 are only written by the wavefronts on the 14:45 row)
+# inside the daily rainflow pass (stamps 11, 14, 15, 12, 13 are only written by the wavefronts on the 14:45 row)
 full = buf.reshape(4096, 16)[: min(E, 4096)].astype(np.int64)
 sel = (full[:, 11] > full[:, 7]) & (full[:, 13] > full[:, 11]) & (full[:, 8] > full[:, 13]) & (full[:, 8] - full[:, 7] < 10**6)
 if sel.any():
     f = full[sel]
-    seg = {"second pass entered -> records arrived": f[:, 11] - f[:, 7], "stack walk + cycle stresses": f[:, 12] - f[:, 11],
-           "SEI model (3 exp)": f[:, 13] - f[:, 12], "stores -> exit": f[:, 8] - f[:, 13]}
-    print(f"daily evaluation, {int(sel.sum())} wavefronts:", {k: (int(np.median(v)), int(np.percentile(v, 90))) for k, v in seg.items()})
-
-if (full[:, 14] > full[:, 6]).any():  # split push: stamp 14 = env-level work done, before the second half of the lane's step
-    m14 = (full[:, 14] > full[:, 6]) & (full[:, 7] > full[:, 14])
-    print("split step: reductions + leader", int(np.median(full[m14, 14] - full[m14, 6])), " finish push + state stores",
-          int(np.median(full[m14, 7] - full[m14, 14])), "p90", int(np.percentile(full[m14, 7] - full[m14, 14], 90)))
-# inside the auto-reset of an env whose episode ended in this step (stamps 14, 15)
-sel = (full[:, 14] > full[:, 7]) & (full[:, 15] > full[:, 14]) & (full[:, 8] > full[:, 15]) & (full[:, 8] - full[:, 7] < 10**6)
-if sel.any():
-    f = full[sel]
-    seg = {"second pass entered -> start row chosen": f[:, 14] - f[:, 7], "table records -> state written": f[:, 15] - f[:, 14],
-           "observation tail, env record -> exit": f[:, 8] - f[:, 15]}
-    print(f"auto-reset, {int(sel.sum())} wavefronts:", {k: (int(np.median(v)), int(np.percentile(v, 90))) for k, v in seg.items()})
+    lds = (f[:, 14] > f[:, 11]) & (f[:, 15] > f[:, 14])
+    seg = {"pass entered -> area taken, copy requested": f[:, 11] - f[:, 7]}
+    if lds.any():
+        g = f[lds]
+        seg.update({"copy into the LDS": g[:, 14] - g[:, 11], "count of the pending points": g[:, 15] - g[:, 14],
+                    "forced point + residuals": g[:, 12] - g[:, 15]})
+    seg.update({"SEI model (3 exp)": f[:, 13] - f[:, 12], "write-back -> exit": f[:, 8] - f[:, 13]})
+    print(f"daily pass, {int(sel.sum())} wavefronts ({int(lds.sum())} through the LDS):",
+          {k: (int(np.median(v)), int(np.percentile(v, 90)), int(v.max())) for k, v in seg.items()}, "(median, p90, max cycles)")
 
 # the launch's timeline from the chip-wide 100 MHz counter (10 ns ticks)
 rt = buf.reshape(4096, 16)[: min(E, 4096), 9:11].astype(np.int64)
@@ -102,3 +102,37 @@ slow = np.argsort(tt)[-max(8, len(tt) // 50):]
 print("slowest 2 % of the ordinary wavefronts, median cycles per segment (all ordinary in brackets):")
 for k, n in enumerate(names):
     print(f"  {n:34s} {np.median(d[slow, k]):8.0f}   ({np.median(d[ordn, k]):.0f})")
+
+# exit time by class: plain / daily row / episode end (+ auto-reset), from the chip-wide counter
+daily = (rt_all[:, 11] > rt_all[:, 0]) & (rt_all[:, 8] > rt_all[:, 11])
+heavy_tail = (rt_all[:, 8] - rt_all[:, 7]) > 2500
+cls = np.where(daily, 1, np.where(heavy_tail, 2, 0))
+print("exit time by class [us from the first wave's entry] (n, entry median, exit median / p90 / max, life median / max):")
+for k, name in enumerate(("plain", "daily row", "episode end + reset")):
+    m = ok & (cls == k)
+    if m.any():
+        en, ex = (rt_all[m, 9] - t0) / 100.0, (rt_all[m, 10] - t0) / 100.0
+        print(f"  {name:20s} n={int(m.sum()):5d} entry {np.median(en):5.2f}  exit {np.median(ex):5.2f} / {np.percentile(ex, 90):5.2f} / {ex.max():5.2f}"
+              f"  life {np.median(ex - en):5.2f} / {(ex - en).max():5.2f}")
+
+# counting waves (rainflow count of the pending points inside the step, stamps 14 / 15 between 4 and 5)
+cw = (rt_all[:, 14] > rt_all[:, 4]) & (rt_all[:, 15] > rt_all[:, 14]) & (rt_all[:, 5] >= rt_all[:, 15]) & (rt_all[:, 4] > rt_all[:, 0])
+if cw.any():
+    f = rt_all[cw]
+    seg = {"money terms done -> window in the LDS (wait)": f[:, 14] - f[:, 4], "count + write-back": f[:, 15] - f[:, 14],
+           "whole wave": f[:, 8] - f[:, 0]}
+    print(f"counting wavefronts: {int(cw.sum())}:", {k: (int(np.median(v)), int(np.percentile(v, 90)), int(v.max())) for k, v in seg.items()},
+          "(median, p90, max cycles);  non-counting whole wave median", int(np.median((rt_all[~cw & ok, 8] - rt_all[~cw & ok, 0]))))
+    m = ok & cw
+    en, ex = (rt_all[m, 9] - t0) / 100.0, (rt_all[m, 10] - t0) / 100.0
+    print(f"  counting waves exit [us] median {np.median(ex):5.2f} p90 {np.percentile(ex, 90):5.2f} max {ex.max():5.2f}")
+
+if cw.any():
+    f = rt_all[cw]
+    names2 = ["0 entry", "1 head", "2 hot ready (+window requested)", "3 state machine done", "4 window waited for, obs stored, money done", "14 count starts", "15 count + write-back done",
+              "5 ev_finish", "6 before reductions", "7 leader done", "8 exit"]
+    order = [0, 1, 2, 3, 4, 14, 15, 5, 6, 7, 8]
+    print("counting wavefronts, median cycles between consecutive stamps:")
+    for a_, b_, n_ in zip(order[:-1], order[1:], names2[1:]):
+        dlt = f[:, b_] - f[:, a_]
+        print(f"   -> {n_:52s} {int(np.median(dlt)):7d}  p90 {int(np.percentile(dlt, 90)):7d}  max {int(dlt.max()):7d}")
