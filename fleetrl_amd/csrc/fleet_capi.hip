@@ -113,9 +113,9 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
-  // the size of the EV's reversal log travels in a 22-bit field of the hot record (fleet_device.h HOT_PACK)
+  // the size of the EV's rainflow log travels in a 25-bit field of the hot record (fleet_device.h HOT_PACK)
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
-    return "rainflow/SEI degradation: episode_steps exceeds 4.19 million (the packed size of the reversal log is 22 bits wide)";
+    return "rainflow/SEI degradation: episode_steps exceeds 33 million (the packed size of the rainflow log is 25 bits wide)";
   // ... and the kernels address an EV's rainflow row as (its env's rows) + a 32-bit byte offset
   if (p->deg_mode == FLEET_DEG_RAINFLOW && (uint64_t)p->num_cars * ((uint64_t)p->episode_steps + 24) * 8ull >= (1ull << 32))
     return "rainflow/SEI degradation: num_cars x episode_steps too large (the rainflow rows of one env exceed 4 GiB)";
@@ -124,7 +124,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     for (int r = 0; r < p->table_rows; ++r) {
       if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
       if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r > FLEET_MAX_STACK_ROWS - 3)
-        return "rainflow/SEI degradation: an episode spans more than 4.19 million rows (the packed size of the reversal log is 22 bits wide)";
+        return "rainflow/SEI degradation: an episode spans more than 33 million rows (the packed size of the rainflow log is 25 bits wide)";
     }
   if (t->lookahead_row)
     for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
@@ -430,33 +430,11 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
       b->error = "num_cars x episode length: the rainflow rows of one env exceed 4 GiB";
       return FLEET_ERR_INVALID;
     }
-    // When the pending reversal points are counted (fleet_kernels.hip rf_count).  The count itself is cheap; what a launch pays
-    // for is (a) the lines of the EV's private row every count touches and (b) its slowest wavefront.
-    //  * "daily": on the daily row only, where the reference counts, through the workgroup's one LDS area (64 entries per lane,
-    //    one wavefront at a time).  Fewest lines; a counting wavefront does a whole day's points at once, which is free when
-    //    its workgroup slot is refilled by the next generation of wavefronts, or when a wavefront steps K times anyway.
-    //  * "cadence 8": on every 8th table row as well (phased so that the row before the shipped data's 14:45 row counts),
-    //    a few turns at a time, through a window of the wavefront's own.  For one step per launch on a batch that is a single
-    //    generation of resident wavefronts (<= 4096 of them), where a launch lasts as long as its slowest wavefront.
-    // FLEET_RF_CADENCE (0 = daily; 2, 4, 8) overrides, for experiments: the results do not depend on it.
-    {
-      const long waves = (long)E * ((N + 63) / 64);
-      int cad = (waves <= 4096 && N <= 64) ? 8 : 0;
-      if (const char* ov = getenv("FLEET_RF_CADENCE")) {
-        const int v = atoi(ov);
-        if (v == 0 || v == 2 || v == 4 || v == 8) cad = v;
-      }
-      d.rf_cad_mask = cad ? cad - 1 : 0;
-      d.rf_cad_phase = cad ? (58 & (cad - 1)) : -1;
-      d.rf_win_units = cad ? 9 : 32;
-      d.rf_locked = cad ? 0 : 1;
-    }
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
     // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0; reset() seeds the log
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
     h0.rf_len = 1;
-    h0.sz = 1;
     std::vector<RfHdr> hdrs(EN, h0);
     HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, hdrs.data(), sizeof(RfHdr), sizeof(RfHdr), EN,
                                 hipMemcpyHostToDevice, b->stream));

@@ -10,9 +10,8 @@
 //     an EV crosses a schedule event, and then for the row AFTER next -- off the step's critical path;
 //   * everything a group needs per env and step sits in ONE 64-byte record (16-byte head + leader statistics);
 //   * the env-level observation blocks and the physics scalars of a time row sit in contiguous rows;
-//   * the SOC history the daily degradation pass needs is an append-only log of reversal points per EV (128-byte-aligned
-//     rows): a step that finds a reversal point STORES it and reads nothing; cycle counting happens where the reference
-//     does it, on the daily row.
+//   * rarely touched state (rainflow accumulators + stack, SEI model) sits in per-EV 128-byte-aligned rows / 32-byte
+//     records so an event touches one cache line and the hot path none.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -78,27 +77,26 @@ __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
 //     of the table, hand-made tables) or a reset that starts from soc == -0.0 -- keeps x = soc and puts soc_deg into the
 //     soc_deg plane: FROZEN | INPLANE (read through a dependent load; it does not occur inside the reference's episodes).
 // Everything else that changes rarely has planes of its own that are only written when it changes: `soh` (daily), the
-// schedule record of the next row `run` (at schedule events), the reversal log of the rainflow count (one word appended
-// when the SOC slope changes sign).
+// schedule record of the next row `run` (at schedule events), the rainflow log (one word appended when the SOC slope
+// changes sign).
 struct Hot {
   double x;        // episode.soc and / or episode.soc_deg, see above
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
-  uint32_t bits;   // [21:0] entries of the EV's reversal log (counted stack + pending points), [25:22] how many of them are pending
-                   // (appended since the last count; saturates at 15: only "none" is acted on, RfHdr.sz is the authority), [26] INPLANE, [28:27] sign of the last SOC slope (0 none, 1 up, 2 down),
-                   // [29] FROZEN, [30] There at the current time row (carried so the step needs no table read for it),
-                   // [31] sticky "target_soc = 0.9" flag (quirk Q7)
+  uint32_t bits;   // [24:0] entries of the EV's rainflow log (the three-point stack, plus the pending point), [25] PENDING: the
+                   // newest entry has not been counted yet, [26] INPLANE, [28:27] sign of the last SOC slope (0 none, 1 up,
+                   // 2 down), [29] FROZEN, [30] There at the current time row (carried so the step needs no table read for
+                   // it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
-#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFu))
-#define HOT_PEND(b) ((int)(((b) >> 22) & 15u))
+#define HOT_TAIL(b) ((int)((b) & 0x1FFFFFFu))
+#define HOT_PEND(b) ((int)(((b) >> 25) & 1u))
 #define HOT_INPLANE(b) ((((b) >> 26) & 1u) != 0u)
 #define HOT_SGN(b) ((int)(((b) >> 27) & 3u))
 #define HOT_FROZEN(b) ((((b) >> 29) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define FLEET_MAX_STACK_ROWS 0x3FFFFF  // 22-bit log size: 4.19 million samples per episode (119 years of 15-minute steps)
-#define FLEET_MAX_PENDING 15           // 4-bit pending count (saturating)
+#define FLEET_MAX_STACK_ROWS 0x1FFFFFF  // 25-bit log size: 33 million samples per episode
 #define HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090)                                                            \
-  (((uint32_t)(tail) & 0x3FFFFFu) | (((uint32_t)(pend) & 15u) << 22) | ((inplane) ? 0x4000000u : 0u) |                    \
+  (((uint32_t)(tail) & 0x1FFFFFFu) | (((uint32_t)(pend) & 1u) << 25) | ((inplane) ? 0x4000000u : 0u) |                    \
    (((uint32_t)(sgn) & 3u) << 27) | ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) |                    \
    ((t090) ? 0x80000000u : 0u))
 // episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
@@ -139,29 +137,30 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Rainflow row of (env e, EV c), 128-byte aligned: a 32-byte header followed by the EV's REVERSAL LOG.
+// Rainflow row of (env e, EV c), 128-byte aligned: a 32-byte header followed by the EV's log of reversal points.
 // The reference keeps every SOC sample of the episode and re-counts the cycles of the whole history on the daily 14:45 row
-// (rainflow.extract_cycles over LogDataDeg.soc_log, rainflow_sei_degradation.py:130-135); between two daily rows nothing of the
-// count is observable.  Three-point counting only ever looks at reversal points, in order, so a step that finds one (strict
-// sign change of the SOC slope, rainflow.reversals) APPENDS it to the log -- one 8-byte store, no load:
-//   log[0 .. sz)      the three-point stack after the last count (the points no closed cycle has consumed)
-//   log[sz .. tail)   reversal points appended since, not yet counted      (tail lives in Hot.bits, sz in the header)
-// The pending points are counted -- pushed through the three-point rule in order, in place: the stack can never be longer than
-// the number of points counted so far -- on the daily row, where the reference counts, and (one step per launch on a batch
-// that is a single generation of wavefronts) on every 8th table row as well, by the whole wavefront at once (the trigger is a
-// property of the env's time row, so a wavefront that is one env either counts or does not), in an LDS area the rows' newest
-// entries are staged into.  The accumulators over the closed cycles (count, sum of means, stress sum of the
-// reference's slice) are folded in the same order whenever the points are counted, so the result does not depend on WHEN.
+// (rainflow.extract_cycles over LogDataDeg.soc_log, rainflow_sei_degradation.py:130-135).  Three-point counting only ever looks
+// at reversal points, in order, so the kernel keeps the three-point STACK (the points no closed cycle has consumed yet) and the
+// accumulators over the closed cycles, and feeds them one reversal point at a time:
+//   log[0 .. tail)   the stack, oldest point first; when Hot.bits says PENDING its newest entry has been appended by the last
+//                    step (one store, nothing read) and is pushed through the three-point rule by the next one
+// Everything a count touches -- accumulators, the point, the four entries below it -- sits in ONE cache line for the usual
+// stack depths; a step that neither appends nor counts never touches the row.
 struct RfHdr {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
   int32_t nc;       // closed cycles this episode
   int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6: reset() keeps it)
-  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_count)
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_count_one)
   float maxdod;     // largest range among those cycles (the reference's "DoD too large" test, :164-167)
-  int32_t sz;       // counted stack: log[0 .. sz); log[sz .. tail) are the pending points
+  int32_t pad;
+};
+struct RfAcc {  // bytes 0..15 of RfHdr: what every closed cycle reads and writes
+  double mean_sum;
+  int32_t nc;
+  int32_t rf_len;
 };
 #define RF_HDR_WORDS 4  // doubles of the header; the log follows
-static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS, "RfHdr layout");
+static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAcc) == 16, "RfHdr layout");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc
@@ -236,10 +235,6 @@ struct FleetDev {
   double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (4 doubles) followed by the reversal log, EV-major and
                       // 128-byte aligned
   int rf_row_stride;  // doubles per row (multiple of 16)
-  // rainflow counting rows: table rows r with (r & rf_cad_mask) == rf_cad_phase, and the daily row (rf_cad_phase < 0: the
-  // daily row only); rf_win_units = 16-byte units of a lane's log staged in the LDS: 9 (the wavefront's own window, 18 entries)
-  // or 32 (the workgroup's one area, 64 entries, taken by one wavefront at a time: rf_locked)
-  int rf_cad_mask, rf_cad_phase, rf_win_units, rf_locked;
 };
 
 // launchers implemented in fleet_kernels.hip

@@ -27,12 +27,13 @@
 // observation slots are requested when the head arrives and consumed late (money terms, observation stores).
 //
 // Rainflow without a history replay.  The reference keeps every SOC sample and re-runs rainflow over the whole episode
-// history every simulated day.  Three-point counting only looks at reversal points, in order: a step that finds one (the SOC
-// slope changes sign) appends it to the EV's reversal log in HBM -- ONE 8-byte store, nothing is read -- and the daily 14:45
-// pass counts the points appended since the last pass on top of the stack that pass left (rf_count), evaluates the forced
-// last point and the residual half cycles on a *virtual* copy of the stack (registers only) and applies the SEI model, which
-// reproduces the reference's full recount, including its cross-episode bookkeeping (rainflow_length, quirk Q6), at
-// O(new reversal points + stack depth) instead of O(history).
+// history every simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in
+// HBM: closed-cycle count, sum of cycle means, stress sum of the closed cycles that fall into the reference's slice, the stack
+// of reversal points; slope sign and stack size in the hot record) and feeds it ONE reversal point at a time: the step that
+// finds a point appends it (one store), the next step counts it -- with the row requested as soon as the hot record says so,
+// a whole step ahead of its use.  On the daily 14:45 row the forced last point and the residual half cycles are evaluated on
+// a *virtual* copy of the stack (registers only), which reproduces the reference's full recount, including its cross-episode
+// bookkeeping (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
 #include "fleet_device.h"
 
 #ifdef FLEET_STAMPS
@@ -381,261 +382,106 @@ __device__ __forceinline__ bool rf_reversal(double old_deg, double soc_deg, int&
   return rev;
 }
 
-// The reversal point `p` joins the EV's log: one store, nothing is read (struct RfHdr in fleet_device.h).
-__device__ __forceinline__ void rf_append(const FleetDev& d, const EvIx& i, double p, int& tail, int& pend, uint32_t& err) {
+// ---- the rainflow count: deferred by one step ------------------------------------------------------------------------------
+// A step that finds a reversal point APPENDS it to the EV's log (one 8-byte store, nothing is read) and marks it pending in the
+// hot record.  The NEXT step of the EV pushes it through the three-point rule.  What that needs of the EV's row -- the
+// accumulators and the four stack entries below the point -- is known to be needed as soon as the hot record has arrived (the
+// pending bit), i.e. a whole step of arithmetic before it is consumed: the row's round trip is off the wavefront's path.
+// (Round 3 decided and requested in the same step: the request could only leave after the state machine, and a dependent round
+// trip of ~2.7 k cycles sat between it and the end of the step on every wavefront, profiles/r03_experiments/stamps_*.)
+// A point that closes no cycle is already where it belongs -- it IS the new top of the stack -- so the count of such a point
+// stores nothing at all.  On the daily row the pending point and the point of the step itself are both counted before the
+// evaluation, so the evaluation sees exactly the reference's cycle list.
+// (Counting lazily in larger batches -- every 8th row, or only on the daily row, in an LDS copy of the log -- was built and
+// measured this round: the total work is the same, but it falls on a few wavefronts, which then end the launch; DESIGN.md
+// section 9, profiles/r04_experiments/lazy_*.)
+__device__ __forceinline__ void rf_append(const FleetDev& d, const EvIx& i, double p, int& tail, uint32_t& err) {
   if (tail >= d.stack_cap) {  // cannot happen (points <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
   *rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail)) = p;
   tail += 1;
-  pend = pend < FLEET_MAX_PENDING ? pend + 1 : pend;
 }
 
-// ---- counting the pending points ---------------------------------------------------------------------------------------
-// WHEN: on every table row r with (r & 7) == 2 and on the daily row (FLEET_TFLAG_DEG).  The shipped data's daily row is 14:45
-// = row 59 of the day, and 58 & 7 == 2: the row before it is a counting row, so the daily pass itself finds at most the
-// point of its own step pending.  The trigger is a property of the env's time row: for one env per wavefront the whole
-// wavefront either counts or does not, and 7 of 8 step nothing but the append above.  (With the count at push time, round 3,
-// EVERY wavefront had a pushing lane on every step: a dependent round trip to the EV's row and the closure loop on every
-// wavefront's path; with the count on the daily row only, 1 % of the wavefronts carry a 20 k-cycle pass and end the launch
-// 13 us after everybody else -- both measured, profiles/r04_experiments/.)
-// WHERE: in a window of the wavefront's own LDS: the newest kRfWinEntries entries of every lane's log (pending points + the
-// top of the counted stack) are copied there by the memory system (global_load_lds_dwordx4: no registers, all units in
-// flight at once), requested as soon as the lane's hot record -- which holds the log's size -- has arrived, and consumed after
-// the step's own arithmetic: no round trip on the wavefront's path.  Counting walks the log with data-dependent indices, one
-// dependent access per popped point: ~100 cycles from the LDS, a round trip to the L2 from global memory (the L1 does not
-// keep a line its own wavefront has just stored to; 25 us per daily pass measured that way).  Entries below the window -- a
-// cycle closing deeper than the 9+ staged stack entries -- are read from global memory.
-// (the cadence is a launch parameter, FleetDev.rf_cad_mask / rf_cad_phase: WHEN the points are counted does not change any result)
-constexpr int kRfTurns = 4;      // turns of the counting loop a wavefront takes on an ordinary counting row (rf_count_staged)
-constexpr int kRfBacklog = 5;    // ... unless a lane has more points than this pending
-constexpr int kRfWinUnits = 9;     // 16-byte units per lane of a wavefront's own window (18 entries)
-constexpr int kRfAreaUnits = 32;   // ... of the workgroup's one area (64 entries), FleetDev.rf_locked
-constexpr int kRfWaveLdsBytes = kRfWinUnits * 64 * 16;  // unit u of lane r at byte (u * 64 + r) * 16: what global_load_lds produces
-constexpr int kRfLdsBytes = (kBlock / 64) * kRfWaveLdsBytes;
-static_assert(kRfAreaUnits * 64 * 16 <= kRfLdsBytes, "the workgroup's area is carved from the same LDS block as the four windows");
-
-// (LDS pointers carry their address space in the type: a pointer that may be LDS or global -- e.g. the two arms of `ld` merged
-// into one access -- compiles to FLAT instructions, ~1000 cycles per dependent access; measured.)
-typedef __attribute__((address_space(3))) char fleet_lds_char;
-typedef __attribute__((address_space(3))) double fleet_lds_double;
-typedef __attribute__((address_space(3))) fleet_v4f fleet_lds_v4f;
-struct RfWin {
-  fleet_lds_char* col;  // LDS: this lane's column of the wavefront's window (unit u at col + u * 1024)
-  double* lg;           // global: entry 0 of the EV's log
-  int lo;               // first staged entry (even): the window holds log[lo .. lo + cap)
-  int wmin;             // lowest staged entry written (start of the write-back range)
-  int cap;              // entries the window holds (2 * FleetDev.rf_win_units)
-  __device__ __forceinline__ bool staged(int k) const { return (unsigned)(k - lo) < (unsigned)cap; }
-  __device__ __forceinline__ fleet_lds_double* at(int k) const {
-    return reinterpret_cast<fleet_lds_double*>(col + ((k - lo) >> 1) * 1024 + ((k - lo) & 1) * 8);
-  }
-  __device__ __forceinline__ double ld(int k) const {
-    if (__builtin_expect(!staged(k), 0)) return lg[k];  // below the window: a cycle closing deeper than the staged stack
-    return *at(k);
-  }
-  __device__ __forceinline__ void st(int k, double v) {
-    if (__builtin_expect(!staged(k), 0)) {
-      lg[k] = v;
-      return;
-    }
-    *at(k) = v;
-    wmin = k < wmin ? k : wmin;
-  }
+// What the count of the log's newest point needs: the accumulators and the five newest log entries.
+struct RfReq {
+  RfAcc acc;
+  double p, b, a, w0, w1;  // log[T-1] (the point), log[T-2], log[T-3], log[T-4], log[T-5]
 };
-
-// The workgroup's one LDS area (FleetDev.rf_locked) is taken by one wavefront at a time: called by all lanes of a wavefront
-// that count, one of them spins.  A holder never waits for anything but memory, so the lock cannot deadlock.
-__device__ __forceinline__ void rf_area_take(int* lock) {
-  if ((int)(threadIdx.x & 63u) == (int)__ffsll((long long)__ballot(true)) - 1) {
-    while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(8);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void rf_area_release(int* lock) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((int)(threadIdx.x & 63u) == (int)__ffsll((long long)__ballot(true)) - 1) atomicExch(lock, 0);
+__device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int T, RfReq& q) {
+  const double* row = rf_row_of(d, i);
+  const double* lg = row + RF_HDR_WORDS;
+  q.acc = *reinterpret_cast<const RfAcc*>(row);
+  q.p = lg[T - 1];  // T >= 2: a pending point sits on top of at least the episode's first sample
+  q.b = lg[T - 2];
+  q.a = lg[T >= 3 ? T - 3 : 0];  // (shallow stack: any entry of the row, the value is not used)
+  q.w0 = lg[T >= 4 ? T - 4 : 0];
+  q.w1 = lg[T >= 5 ? T - 5 : 0];
 }
 
-// Request the window and the header of one EV (the lane's).  `tail` = entries of its log.
-__device__ __forceinline__ void rf_stage(const FleetDev& d, const EvIx& ix, fleet_lds_char* lds_wave, int units, int tail, RfWin& w, RfHdr& hd) {
-  double* row = rf_row_of(d, ix);
-  int lo = tail - 2 * units;
-  lo = lo < 0 ? 0 : (lo + 1) & ~1;
-  w.col = lds_wave + (threadIdx.x & 63u) * 16;
-  w.lg = row + RF_HDR_WORDS;
-  w.lo = lo;
-  w.wmin = 0x7FFFFFFF;
-  w.cap = 2 * units;
-  const char* src = reinterpret_cast<const char*>(w.lg + lo);
-  const int nu = (tail - lo + 1) >> 1;
-  // (inline assembly instead of __builtin_amdgcn_global_load_lds: with the builtin the compiler puts an `s_waitcnt vmcnt(0)` in
-  // front of EVERY later LDS read of the kernel -- it cannot see that the copy has completed -- and each of them waits for all
-  // the stores the step has issued meanwhile: 11 k cycles per count measured.  The consumer waits once, explicitly.)
-  const unsigned m0_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds_wave);
-#pragma unroll
-  for (int u = 0; u < kRfAreaUnits; ++u) {
-    if (u >= units) break;  // (wave-uniform)
-    if (u < nu)
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0_base + u * 1024), "v"(src + u * 16) : "memory", "m0");
-  }
-  hd = *reinterpret_cast<const RfHdr*>(row);
-}
-
-// The staged pending points log[sz .. tail), then the point of the current step (`has_cur`, not in the log yet), go through
-// the three-point rule (rainflow.extract_cycles, the `while len(points) >= 3` loop) in order, in place, on top of the stack
-// log[0 .. sz).  A closed cycle adds to the episode's cycle count, the sum of cycle means and -- when its index lies in the
-// slice the next evaluation will look at (`iloc[rainflow_length-1 : len-1]`, rainflow_sei_degradation.py:147) -- the stress
-// sum.  Returns the new stack size.
-__device__ __forceinline__ int rf_count_general(RfWin& lg, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur) {
-  const int L = hd.rf_len;
-  int nc = hd.nc;
-  double mean_sum = hd.mean_sum, csum = hd.csum;
-  const int n_pts = (tail - sz) + (has_cur ? 1 : 0);
-  if (n_pts > 0) {
-    double b = lg.ld(sz - 1);  // sz >= 1: reset() seeds the log with the first sample
-    double a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
-    double p_next = (sz < tail) ? lg.ld(sz) : p_cur;
-    int j = sz;
-    for (int q = 0; q < n_pts; ++q, ++j) {
-      const double p = p_next;
-      p_next = (j + 1 < tail) ? lg.ld(j + 1) : p_cur;  // (in flight while this point is counted; no store below reaches j + 1)
-      while (sz >= 2) {  // points [.., a, b, p]
-        const double X = fabs(p - b), Y = fabs(b - a);
-        if (X < Y) break;
-        if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
-          const double rng = fabs(a - b);
-          csum += cycle_stress(rng, 0.5 * (a + b), (sz == 2) ? 0.5 : 1.0, st);
-          hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;  // largest range of the slice ("DoD too large" :164-167 is raised when it is evaluated)
-        }
-        mean_sum += 0.5 * (a + b);
-        nc += 1;
-        if (sz == 2) {  // Y contains the starting point: half cycle, drop the first point -> [b, p]
-          lg.st(0, b);
-          sz = 1;
-          break;
-        }
-        sz -= 2;  // full cycle, drop its two points -> [.., p]
-        b = lg.ld(sz - 1);
-        a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
-      }
-      if (sz != j || j >= tail) lg.st(sz, p);
-      sz += 1;
-      a = b;
-      b = p;
-    }
-  }
-  hd.mean_sum = mean_sum;
-  hd.nc = nc;
-  hd.csum = csum;
-  return sz;
-}
-
-// The same count when the EV's whole log is staged (lo == 0 and the current point still fits: the normal case), as ONE loop
-// whose body has no branches on the common paths: every turn either closes the cycle (a, b) or pushes the point p, chosen per
-// lane with selects, so 64 lanes with 64 different point sequences walk it together (the nested loops of the general form
-// above serialise every lane's path: 11 k cycles per count of eight points measured).  A turn costs ~45 instructions = ~180
-// cycles of the SIMD, whatever the lanes do; a lane needs one turn per point and one per closed cycle.
-//   * the top of the stack lives in registers (b, a); c, d = the two entries below are re-read from the LDS behind every turn:
-//     they are not needed before the turn after next;
-//   * LDS addresses are carried along instead of being rebuilt from indices: log[k] sits at col + (k >> 1) * 1024 + (k & 1) * 8,
-//     so one entry up is `step` = 8 from an even k and 1016 from an odd one (step flips with the parity), two are 1024;
-//   * the half cycle (a closing range that contains the log's very first point) and the stress of a cycle inside the slice of
-//     the next evaluation are rare and take real branches.
-// `turns`: the wavefront stops after that many turns (a launch lasts as long as its slowest wavefront, and the slowest is the one
-// that holds the lane with the longest point sequence of the whole batch) unless a lane's backlog is long; the points that are
-// left stay pending, moved down behind the stack, for the next counting row.
-__device__ __forceinline__ int rf_count_staged(RfWin& w, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur, int turns,
-                                               int& left_out) {
-  const int L = hd.rf_len;
-  int nc = hd.nc;
-  double mean_sum = hd.mean_sum;
-  fleet_lds_char* const col = w.col;
-  auto at = [&](int k) -> fleet_lds_char* { return col + ((k >> 1) << 10) + ((k & 1) << 3); };
-  auto ld = [&](fleet_lds_char* q) -> double { return *reinterpret_cast<const fleet_lds_double*>(q < col ? col : q); };  // (below the
-                                                                          // stack: any staged word, the value is not used)
-  if (has_cur) *reinterpret_cast<fleet_lds_double*>(at(tail)) = p_cur;  // the current step's point joins the staged pending points
-  int left = (tail - sz) + (has_cur ? 1 : 0);                           // points still to be counted
-  fleet_lds_char* As = at(sz);           // where log[sz] goes
-  int step = (sz & 1) ? 1016 : 8;        // As + step = where log[sz + 1] goes
-  fleet_lds_char* Jc = As;               // where the point being counted sits (log[j], j >= sz)
-  int jstep = step;
-  double b = ld(As - 1024 + step), a = ld(As - 1024), c = ld(As - 2048 + step), dd = ld(As - 2048);
-  double p = ld(Jc), p_nx = ld(Jc + jstep);
-  int szmin = sz;
-  while (left > 0 && (turns-- > 0 || left > kRfBacklog)) {
-    const bool closes = (sz >= 2) && !(fabs(p - b) < fabs(b - a));
-    if (__builtin_expect(closes && nc >= L - 1, 0)) {  // only the closed cycles beyond the last evaluation's count carry stress
+// The newest log entry log[T-1] = q.p goes through the three-point rule on top of the stack log[0 .. T-1) (rainflow.
+// extract_cycles, the `while len(points) >= 3` loop).  Returns the stack size afterwards (the point included).
+__device__ __forceinline__ int rf_count_one(const FleetDev& d, const EvIx& i, const RfReq& q, int T) {
+  const double p = q.p;
+  double a = q.a, b = q.b;
+  int size = T;  // points [.., a, b, p]
+  if (!(size >= 3 && !(fabs(p - b) < fabs(b - a)))) return T;  // no cycle closes: the point stays where it is, on top
+  double* row = rf_row_of(d, i);
+  double* lg = row + RF_HDR_WORDS;
+  int nwin = size - 3 > 2 ? 2 : size - 3;  // entries below (a, b) that are in registers: w0 = log[T-4], w1 = log[T-5]
+  const int L = q.acc.rf_len;
+  int nc = q.acc.nc;
+  double mean_sum = q.acc.mean_sum;
+  while (size >= 3) {
+    const double X = fabs(p - b), Y = fabs(b - a);
+    if (X < Y) break;
+    if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
       const double rng = fabs(a - b);
-      hd.csum += cycle_stress(rng, 0.5 * (a + b), (sz == 2) ? 0.5 : 1.0, st);
-      hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;
+      RfHdr* hd = reinterpret_cast<RfHdr*>(row);
+      hd->csum += cycle_stress(rng, 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.self->stress_temp);
+      if ((float)rng > hd->maxdod) hd->maxdod = (float)rng;  // ("DoD too large" :164-167 is raised when the slice is evaluated)
     }
-    mean_sum = fma(a + b, closes ? 0.5 : 0.0, mean_sum);  // += 0.5 * (a + b): the product is exact, so one rounding either way
-    nc += closes ? 1 : 0;
-    // closes, sz == 2: Y contains the starting point: half cycle, drop the first point -> the stack is [b]; p is pushed next turn
-    // closes, sz > 2 : full cycle, drop its two points -> [.., c, d]; p again next turn
-    // else           : push, log[sz] = p
-    const bool half = closes && (sz == 2);
-    if (!closes || half) *reinterpret_cast<fleet_lds_double*>(half ? col : As) = half ? b : p;
-    As = half ? col + 8 : (closes ? As - 1024 : As + step);
-    step = half ? 1016 : (closes ? step : 1024 - step);
-    sz = half ? 1 : sz + (closes ? -2 : 1);
-    szmin = half ? 0 : (sz < szmin ? sz : szmin);
-    a = closes ? dd : b;
-    b = half ? b : (closes ? c : p);
-    c = ld(As - 2048 + step);  // log[sz - 3]  (behind the store above: the LDS serves a wavefront's accesses in order)
-    dd = ld(As - 2048);        // log[sz - 4]
-    Jc = closes ? Jc : Jc + jstep;
-    jstep = closes ? jstep : 1024 - jstep;
-    left -= closes ? 0 : 1;
-    p = closes ? p : p_nx;
-    p_nx = ld(Jc + jstep);     // the point after (at most one entry past the staged points: inside the window)
-  }
-  if (left > 0) {  // the points from Jc on move down to log[sz ..): still pending, in order
-    fleet_lds_char* dst = As;
-    int dstep = step;
-    for (int i = 0; i < left; ++i) {
-      *reinterpret_cast<fleet_lds_double*>(dst) = ld(Jc);
-      dst += dstep;
-      dstep = 1024 - dstep;
-      Jc += jstep;
-      jstep = 1024 - jstep;
+    mean_sum += 0.5 * (a + b);
+    nc += 1;
+    if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> [b, p]
+      lg[0] = b;
+      size = 2;
+    } else {  // full cycle, drop its two points -> [.., p]
+      size -= 2;
+      b = (nwin >= 1) ? q.w0 : lg[size - 2];
+      if (size >= 3) a = (nwin >= 2) ? q.w1 : lg[size - 3];
+      nwin = 0;
     }
   }
-  left_out = left;
-  w.wmin = szmin < w.wmin ? szmin : w.wmin;
-  hd.mean_sum = mean_sum;
-  hd.nc = nc;
-  return sz;
+  lg[size - 1] = p;
+  RfAcc out;
+  out.mean_sum = mean_sum;
+  out.nc = nc;
+  out.rf_len = L;
+  *reinterpret_cast<RfAcc*>(row) = out;
+  return size;
 }
 
-// Returns the counted stack size; `left_out` points stay pending behind it (0 unless `turns` ran out).
-__device__ __forceinline__ int rf_count(RfWin& w, RfHdr& hd, double st, int sz, int tail, bool has_cur, double p_cur, int turns, int& left_out) {
-  if (__builtin_expect(w.lo == 0 && tail < w.cap - 1, 1)) return rf_count_staged(w, hd, st, sz, tail, has_cur, p_cur, turns, left_out);
-  left_out = 0;
-  return rf_count_general(w, hd, st, sz, tail, has_cur, p_cur);
-}
-
-// Header and the rewritten part of the window back to the EV's row (the counted stack is log[0 .. sz)).
-__device__ __forceinline__ void rf_writeback(const RfWin& w, const RfHdr& hd, int sz) {  // sz: entries of the log (stack + still pending)
-  double* row = w.lg - RF_HDR_WORDS;
-  *reinterpret_cast<RfHdr*>(row) = hd;
-  const int u_end = (sz - w.lo + 1) >> 1;  // units holding log[lo .. sz)
-  for (int u = (w.wmin - w.lo) >> 1; u < u_end; ++u)
-    *reinterpret_cast<fleet_v4f*>(w.lg + w.lo + 2 * u) = *reinterpret_cast<const fleet_lds_v4f*>(w.col + u * 1024);
-}
-
-// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212), after the
-// pending points have been counted: `v` = the sample just logged (rainflow.reversals always yields the last sample), `n` =
-// number of logged samples, `sz` = the counted stack log[0 .. sz).
+// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212), every logged
+// reversal point counted: `v` = the sample just logged (rainflow.reversals always yields the last sample), `n` = number of logged
+// samples, the counted stack is log[0 .. sz).
 //   1. the forced last point and the residual half cycles are evaluated on a virtual copy of the stack (vt, vh, registers);
 //      the counted state is not modified by them;
 //   2. the SEI model, when the cycle list has grown beyond rainflow_length (:144).
-__device__ __forceinline__ double rf_evaluate(const RfWin& lg, RfHdr& hd, SeiRec& sr, double st, double v, int n, int sz, uint32_t& err,
-                                            double dt_hours) {
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int sz, uint32_t& err, double dt_hours) {
+  const size_t i = ix.flat();
+  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
+  const double* lg = row + RF_HDR_WORDS;
+  // everything this needs from memory is requested up front (one round trip)
+  RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
+  SeiRec sr = d.sei[i];
+  double b = lg[sz - 1];
+  double a = lg[sz >= 2 ? sz - 2 : 0];
   const int L = hd.rf_len, nc = hd.nc;
-  double max_dod = (double)hd.maxdod;  // over the closed cycles of the slice (rf_count; rounded to float32: the test is `> 5`)
+  const double st = d.stress_temp;
+  FLEET_STAMP(11);
+  double max_dod = (double)hd.maxdod;  // over the closed cycles of the slice (rf_count_one; rounded to float32: the test is `> 5`)
   int nv = 0;
   double vmean = 0.0, vsum = 0.0, pend = 0.0;
   bool has_pend = false;
@@ -654,8 +500,6 @@ __device__ __forceinline__ double rf_evaluate(const RfWin& lg, RfHdr& hd, SeiRec
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
     int vt = sz, vh = 0;
     int size = vt - vh + 1;
-    double b = lg.ld(sz - 1);
-    double a = (sz >= 2) ? lg.ld(sz - 2) : 0.0;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -666,14 +510,14 @@ __device__ __forceinline__ double rf_evaluate(const RfWin& lg, RfHdr& hd, SeiRec
       } else {
         vt -= 2;
         size -= 2;
-        b = lg.ld(vt - 1);
-        a = (size >= 3) ? lg.ld(vt - 2) : 0.0;
+        b = lg[vt - 1];
+        a = (size >= 3) ? lg[vt - 2] : 0.0;
       }
     }
     // remaining ranges are half cycles: log[vh .. vt) followed by the forced point
-    double prev = lg.ld(vh);
+    double prev = lg[vh];
     for (int j = vh + 1; j < vt; ++j) {
-      const double cur = lg.ld(j);
+      const double cur = lg[j];
       emit(prev, cur, 0.5);
       prev = cur;
     }
@@ -701,10 +545,12 @@ __device__ __forceinline__ double rf_evaluate(const RfWin& lg, RfHdr& hd, SeiRec
     hd.rf_len = len;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
     hd.csum = 0.0;
     hd.maxdod = 0.0f;
+    *reinterpret_cast<RfHdr*>(row) = hd;
   }
   FLEET_STAMP(13);
   const double s = sr.sei_soh - degradation;
   sr.sei_soh = s;
+  d.sei[i] = sr;
   if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
 }
@@ -791,7 +637,6 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
       hd.nc = 0;
       hd.csum = 0.0;
       hd.maxdod = 0.0f;
-      hd.sz = 1;
       *reinterpret_cast<RfHdr*>(row) = hd;
       row[RF_HDR_WORDS] = soc_deg;  // the log is [soc_deg]: the first sample is the first reversal point
     }
@@ -846,29 +691,29 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
-// The tail of an EV's step: the rainflow log (append, or -- on a counting row -- the count of the pending points), the linear
-// model's daily update, the data-log row, and the stores of the state records that changed.
-//   `counts`: the lane's window and header were requested (rf_stage) when its hot record arrived; `sz_out` = the counted stack.
+// The tail of an EV's step: the rainflow log (the count of the point the last step appended, the append of the point this step
+// found), the linear model's daily update, the data-log row, and the stores of the state records that changed.
+//   `pend`: the log's newest entry is pending, and `rq` holds what its count needs (requested when the hot record arrived);
+//   `sz_out` = entries of the log afterwards (on the daily row all of them counted).
 template <int DEG>
 __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, bool rev,
-                                          bool counts, RfWin& win, RfHdr& rhd, int tail, int pend, int sgn, double soc, double soc_deg,
-                                          double old_deg, float hl, uint32_t there1, bool t090, bool inplane, bool crosses, const SegRec& nr,
-                                          double soh0, double a, double en, bool logs, size_t lrow, const Hot& h_in, uint32_t& err, int& sz_out) {
+                                          const RfReq& rq, int tail, int pend, int sgn, double soc, double soc_deg, double old_deg, float hl,
+                                          uint32_t there1, bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a,
+                                          double en, bool logs, size_t lrow, const Hot& h_in, uint32_t& err, int& sz_out) {
   double soh = soh0;
   if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
-    if (counts) {
-      FLEET_STAMP(14);
-      const bool cur = rev && (tail < d.self->stack_cap);  // (rare path: its scalars come from the device-resident argument block)
-      if (rev && !cur) err |= FLEET_DEVERR_TABLE_END;
-      int left = 0;
-      const int sz_new = rf_count(win, rhd, d.self->stress_temp, rhd.sz, tail, cur, old_deg, deg_row ? 0x7FFFFFFF : kRfTurns, left);
-      rhd.sz = sz_new;
-      tail = sz_new + left;
-      pend = left < FLEET_MAX_PENDING ? left : FLEET_MAX_PENDING;
-      rf_writeback(win, rhd, tail);
-      FLEET_STAMP(15);
-    } else if (rev) {
-      rf_append(d, i, old_deg, tail, pend, err);
+    if (pend) tail = rf_count_one(d, i, rq, tail);
+    pend = 0;
+    if (rev) {
+      const int before = tail;
+      rf_append(d, i, old_deg, tail, err);
+      pend = tail - before;
+      if (deg_row && pend) {  // the daily evaluation below needs the point of this very step counted as well: a second, dependent
+        RfReq r2;             // round trip, on one step in 96
+        rf_request(*d.self, i, tail, r2);
+        tail = rf_count_one(*d.self, i, r2, tail);
+        pend = 0;
+      }
     }
   }
   sz_out = tail;
@@ -916,16 +761,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
                                                                int32_t* __restrict__ done_count) {
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
-  // LDS window of the rainflow count, one per wavefront (rf_stage / rf_count): no lock, nothing to initialise
-  __shared__ __attribute__((aligned(16))) char rf_lds[DEG == FLEET_DEG_RAINFLOW ? kRfLdsBytes : 16];
-  __shared__ int rf_lock;
-  const bool rf_locked = (DEG == FLEET_DEG_RAINFLOW) && (d.rf_locked != 0);
-  if (rf_locked) {  // the workgroup's one area instead of a window per wavefront
-    if (threadIdx.x == 0) rf_lock = 0;
-    __syncthreads();
-  }
-  fleet_lds_char* const rf_lds_wave =
-      (fleet_lds_char*)rf_lds + ((DEG == FLEET_DEG_RAINFLOW && !rf_locked) ? (threadIdx.x >> 6) * kRfWaveLdsBytes : 0);
   const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -1040,8 +875,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     // the few wavefronts with extra work after the step (daily evaluation, episode end + reset) finish last and set the
     // launch's duration: they get issue priority over their SIMD's other wavefronts for the step itself (-3 % per launch)
-    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && (deg_row || ((t1 & d.rf_cad_mask) == d.rf_cad_phase) && d.rf_cad_mask >= 3)) || is_done))
-      __builtin_amdgcn_s_setprio(3);
+    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
     const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
 
     // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
@@ -1086,10 +920,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
     double sei_sample = 0.0, sei_soh = 0.0;
     int sei_sz = 0;
-    RfWin sei_win = {nullptr, nullptr, 0, 0, 0};
-    RfHdr sei_hd = {0.0, 0, 0, 0.0, 0.0f, 0};
-    // rainflow: is the row this step advances to a counting row of the env (rf_count)?
-    const bool cnt_step = (DEG == FLEET_DEG_RAINFLOW) && (deg_row || ((t1 & d.rf_cad_mask) == d.rf_cad_phase));
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     // Several EVs per lane, one step per launch (N > 64): the lane's NEXT EV's records are requested before the current EV is
     // worked on (software pipelining of the lane loop) -- otherwise every turn of the loop starts with a memory round trip
@@ -1123,15 +953,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
       if (inplane) old_deg = d.soc_deg[i.flat()];
-      // rainflow, counting row: the EV's window and header are requested now and consumed at the end of its step
-      int tail = HOT_TAIL(hb.bits), pend = HOT_PEND(hb.bits), sgn = HOT_SGN(hb.bits);
-      RfWin win = {nullptr, nullptr, 0, 0, 0};
-      RfHdr rhd = {0.0, 0, 0, 0.0, 0.0f, 0};
-      const bool counts = cnt_step && env_ok && (pend > 0 || deg_row);  // (the daily pass needs the stack in any case)
-      if (counts) {
-        if (rf_locked) rf_area_take(&rf_lock);
-        rf_stage(d, i, rf_lds_wave, d.rf_win_units, tail, win, rhd);
-      }
+      // rainflow: the count of a pending point is requested now and consumed at the end of the EV's step
+      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+      const int pend = (DEG == FLEET_DEG_RAINFLOW && env_ok) ? HOT_PEND(hb.bits) : 0;
+      RfReq rq;
+      if (pend) rf_request(d, i, tail, rq);
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -1227,10 +1053,6 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const bool rev = (DEG == FLEET_DEG_RAINFLOW) && rf_reversal(old_deg, soc_deg, sgn);
 
       FLEET_STAMP(3);
-      // (counting row: the LDS copy requested when the hot record arrived is waited for HERE, while nothing but loads is
-      // outstanding -- behind the observation stores the same wait would also wait for every one of them to be acknowledged; the
-      // copy is not a register load the compiler tracks)
-      if (DEG == FLEET_DEG_RAINFLOW && cnt_step) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
       const double tgt_obs = t090 ? 0.9 : d.target_soc;  // the target the observer sees: after this step's sticky update
       if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, tgt_obs, tb1);
@@ -1247,15 +1069,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       int sz_out;
-      ev_finish<DEG>(d, i, c, N, env_ok, deg_row, dt_step, rev, counts, win, rhd, tail, pend, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090,
-                     inplane, crosses, nr, soh0, a, en, logs, lrow, hb, err, sz_out);
-      if (WIDE && counts && rf_locked) rf_area_release(&rf_lock);  // (several EVs per lane: the daily pass below stages again)
-      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {  // what the daily pass needs of the lane's EV stays in registers (and in the LDS)
+      ev_finish<DEG>(d, i, c, N, env_ok, deg_row, dt_step, rev, rq, tail, pend, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane, crosses,
+                     nr, soh0, a, en, logs, lrow, hb, err, sz_out);
+      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {  // what the daily pass needs of the lane's EV stays in registers
         sei_sample = soc_deg;
         sei_soh = soh0;
         sei_sz = sz_out;
-        sei_win = win;
-        sei_hd = rhd;
       }
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
@@ -1310,28 +1129,19 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers.  One step in 96, and wave-uniform for
-    // G == 64.  The pending points were counted with the step (ev_finish); the counted stack is still in the wavefront's LDS
-    // window when a lane owns one EV.
+    // G == 64.  Every reversal point has been counted by the step (ev_finish).
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
       for (int c = g; c < N; c += G) {
         const EvIx ix = {(size_t)e * N, (unsigned)c};
         const size_t i = ix.flat();
         double soh_new = sei_soh;
-        if (WIDE) {  // several EVs per lane: re-read the few words from the records this lane has just stored, stage again
+        if (WIDE) {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
           sei_sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
           sei_sz = HOT_TAIL(hb.bits);
           soh_new = d.soh[i];
-          if (rf_locked) rf_area_take(&rf_lock);
-          rf_stage(*d.self, ix, rf_lds_wave, d.rf_win_units, sei_sz, sei_win, sei_hd);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        SeiRec sr = d.sei[i];
-        FLEET_STAMP(11);
-        const double deg = rf_evaluate(sei_win, sei_hd, sr, d.self->stress_temp, sei_sample, r.nsamp, sei_sz, err, dt_step);
-        *reinterpret_cast<RfHdr*>(sei_win.lg - RF_HDR_WORDS) = sei_hd;
-        if (rf_locked) rf_area_release(&rf_lock);
-        d.sei[i] = sr;
+        const double deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_sz, err, dt_step);
         soh_new -= deg;
         d.soh[i] = soh_new;
         if (logs) {
@@ -1510,21 +1320,14 @@ int group_size(int N) {
 }
 
 template <int G, int DEG>
-hipError_t launch_step_gd(const FleetDev& d_in, const void* actions, int act_dtype, int K, float* obs, double* reward,
+hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
-  FleetDev d = d_in;
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
-  if (!single) {  // a wavefront that steps K times (or skips rows) counts its reversal points on the daily row only (fleet_create)
-    d.rf_cad_mask = 0;
-    d.rf_cad_phase = -1;
-    d.rf_win_units = kRfAreaUnits;
-    d.rf_locked = 1;
-  }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,
