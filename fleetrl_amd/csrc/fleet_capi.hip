@@ -113,9 +113,9 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
-  // the size of the EV's rainflow log travels in a 25-bit field of the hot record (fleet_device.h HOT_PACK)
+  // the rainflow stack size travels in a 26-bit field of the hot record (fleet_device.h HOT_PACK)
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
-    return "rainflow/SEI degradation: episode_steps exceeds 33 million (the packed size of the rainflow log is 25 bits wide)";
+    return "rainflow/SEI degradation: episode_steps exceeds 67 million (the packed rainflow stack size is 26 bits wide)";
   // ... and the kernels address an EV's rainflow row as (its env's rows) + a 32-bit byte offset
   if (p->deg_mode == FLEET_DEG_RAINFLOW && (uint64_t)p->num_cars * ((uint64_t)p->episode_steps + 24) * 8ull >= (1ull << 32))
     return "rainflow/SEI degradation: num_cars x episode_steps too large (the rainflow rows of one env exceed 4 GiB)";
@@ -124,7 +124,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     for (int r = 0; r < p->table_rows; ++r) {
       if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
       if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r > FLEET_MAX_STACK_ROWS - 3)
-        return "rainflow/SEI degradation: an episode spans more than 33 million rows (the packed size of the rainflow log is 25 bits wide)";
+        return "rainflow/SEI degradation: an episode spans more than 67 million rows (the packed rainflow stack size is 26 bits wide)";
     }
   if (t->lookahead_row)
     for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
@@ -354,16 +354,16 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.penalty_overload = p->penalty_overloading; d.fully_charged_reward = p->fully_charged_reward;
   d.target_soc = p->target_soc; d.target_soc_lunch = p->target_soc_lunch; d.eps = p->eps;
   d.max_time_left = p->max_time_left;
-  // auxiliary observation slots: divisions by constants become multiplications by the correctly rounded reciprocal
+  // auxiliary observation slots: divisions by constants become multiplications by the correctly rounded quotient / reciprocal
   d.hn_scale = p->batt_cap_nominal / (p->evse_power * p->charging_eff);
-  d.inv_max_soc = p->normalize ? 1.0 / p->max_soc : 1.0;
-  d.inv_max_hours_needed = p->normalize ? 1.0 / p->max_hours_needed : 1.0;
-  d.inv_max_laxity = p->normalize ? 1.0 / p->max_laxity : 1.0;
 
   FleetCold& cd = b->cold_host;
   cd.min_laxity = p->min_laxity; cd.def_soc = p->def_soc; cd.init_soh = p->init_soh; cd.temperature = p->temperature;
   cd.dt = p->dt; cd.batt_cap_nominal = p->batt_cap_nominal; cd.hn_denominator = p->evse_power * p->charging_eff;
   cd.max_soc = p->max_soc; cd.max_hours_needed = p->max_hours_needed; cd.max_laxity = p->max_laxity;
+  cd.inv_max_soc = p->normalize ? 1.0 / p->max_soc : 1.0;
+  cd.inv_max_hours_needed = p->normalize ? 1.0 / p->max_hours_needed : 1.0;
+  cd.inv_max_laxity = p->normalize ? 1.0 / p->max_laxity : 1.0;
   cd.seed = p->seed; cd.picker_mode = p->picker_mode; cd.start_lo = p->start_lo; cd.start_hi = p->start_hi;
   cd.env_id_offset = p->env_id_offset; cd.sched_n = 0; cd.normalize = p->normalize; cd.sched = nullptr;
 
@@ -431,7 +431,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
       return FLEET_ERR_INVALID;
     }
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
-    // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0; reset() seeds the log
+    // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
     h0.rf_len = 1;

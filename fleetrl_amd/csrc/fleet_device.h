@@ -77,28 +77,24 @@ __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
 //     of the table, hand-made tables) or a reset that starts from soc == -0.0 -- keeps x = soc and puts soc_deg into the
 //     soc_deg plane: FROZEN | INPLANE (read through a dependent load; it does not occur inside the reference's episodes).
 // Everything else that changes rarely has planes of its own that are only written when it changes: `soh` (daily), the
-// schedule record of the next row `run` (at schedule events), the rainflow log (one word appended when the SOC slope
-// changes sign).
+// schedule record of the next row `run` (at schedule events), the rainflow stack top `rf_top` (when a reversal is pushed).
 struct Hot {
   double x;        // episode.soc and / or episode.soc_deg, see above
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
-  uint32_t bits;   // [24:0] entries of the EV's rainflow log (the three-point stack, plus the pending point), [25] PENDING: the
-                   // newest entry has not been counted yet, [26] INPLANE, [28:27] sign of the last SOC slope (0 none, 1 up,
-                   // 2 down), [29] FROZEN, [30] There at the current time row (carried so the step needs no table read for
-                   // it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
+  uint32_t bits;   // [25:0] rainflow stack size (the stack always starts at slot 0), [26] INPLANE, [28:27] sign of the last
+                   // SOC slope (0 none, 1 up, 2 down), [29] FROZEN, [30] There at the current time row (carried so the
+                   // step needs no table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
-#define HOT_TAIL(b) ((int)((b) & 0x1FFFFFFu))
-#define HOT_PEND(b) ((int)(((b) >> 25) & 1u))
+#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFFu))
 #define HOT_INPLANE(b) ((((b) >> 26) & 1u) != 0u)
 #define HOT_SGN(b) ((int)(((b) >> 27) & 3u))
 #define HOT_FROZEN(b) ((((b) >> 29) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define FLEET_MAX_STACK_ROWS 0x1FFFFFF  // 25-bit log size: 33 million samples per episode
-#define HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090)                                                            \
-  (((uint32_t)(tail) & 0x1FFFFFFu) | (((uint32_t)(pend) & 1u) << 25) | ((inplane) ? 0x4000000u : 0u) |                    \
-   (((uint32_t)(sgn) & 3u) << 27) | ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) |                    \
-   ((t090) ? 0x80000000u : 0u))
+#define FLEET_MAX_STACK_ROWS 0x3FFFFFF  // 26-bit stack size: 67 million samples per episode
+#define HOT_PACK(tail, sgn, frozen, inplane, there, t090)                                                                 \
+  (((uint32_t)(tail) & 0x3FFFFFFu) | ((inplane) ? 0x4000000u : 0u) | (((uint32_t)(sgn) & 3u) << 27) |                    \
+   ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
 // episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
 #define HOT_SOC(h) ((HOT_FROZEN((h).bits) && !HOT_INPLANE((h).bits)) ? 0.0 : (h).x)
 
@@ -137,30 +133,34 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Rainflow row of (env e, EV c), 128-byte aligned: a 32-byte header followed by the EV's log of reversal points.
-// The reference keeps every SOC sample of the episode and re-counts the cycles of the whole history on the daily 14:45 row
-// (rainflow.extract_cycles over LogDataDeg.soc_log, rainflow_sei_degradation.py:130-135).  Three-point counting only ever looks
-// at reversal points, in order, so the kernel keeps the three-point STACK (the points no closed cycle has consumed yet) and the
-// accumulators over the closed cycles, and feeds them one reversal point at a time:
-//   log[0 .. tail)   the stack, oldest point first; when Hot.bits says PENDING its newest entry has been appended by the last
-//                    step (one store, nothing read) and is pushed through the three-point rule by the next one
-// Everything a count touches -- accumulators, the point, the four entries below it -- sits in ONE cache line for the usual
-// stack depths; a step that neither appends nor counts never touches the row.
+// Rainflow row of (env e, EV c): a 48-byte header followed by the reversal stack, 128-byte aligned, so that everything a
+// push touches -- accumulators, the two newest stack entries, the entries right below them -- sits in ONE cache line for
+// the usual stack depths.  Nothing of it is read by a step that pushes no reversal point (three steps in four): whether
+// a step pushes is decided from the hot record alone (sign of the last slope), and only then is the row requested.
+//   * `s2` is the ONLY copy of the newest stack entry: the stack words hold the entries below it (stack[0 .. tail-2];
+//     `s1` caches the last of them).  A push that closes no cycle therefore writes one stack word (the displaced old
+//     top), and a push that closes a full cycle writes none (the two popped points vanish, the new point stays in s2).
+//   * what every closure reads and writes sits in the first 16 bytes, the stack top in the next 16.
 struct RfHdr {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
   int32_t nc;       // closed cycles this episode
-  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6: reset() keeps it)
-  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_count_one)
-  float maxdod;     // largest range among those cycles (the reference's "DoD too large" test, :164-167)
-  int32_t pad;
+  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
+  double s1;        // stack[tail-2]
+  double s2;        // stack[tail-1]
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_finish)
+  double pad;
 };
-struct RfAcc {  // bytes 0..15 of RfHdr: what every closed cycle reads and writes
+struct RfAccHead {  // bytes 0..15 of RfHdr
   double mean_sum;
   int32_t nc;
   int32_t rf_len;
 };
-#define RF_HDR_WORDS 4  // doubles of the header; the log follows
-static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAcc) == 16, "RfHdr layout");
+struct RfTop {  // bytes 16..31 of RfHdr
+  double s1;
+  double s2;
+};
+#define RF_HDR_WORDS 6  // doubles of the header; the stack follows
+static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAccHead) == 16 && sizeof(RfTop) == 16, "RfHdr layout");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc
@@ -173,6 +173,7 @@ struct SeiRec {
 struct FleetCold {
   double min_laxity, def_soc, init_soh, temperature, dt;
   double batt_cap_nominal, hn_denominator, max_soc, max_hours_needed, max_laxity;
+  double inv_max_soc, inv_max_hours_needed, inv_max_laxity;  // oracle_normalization.py:127-131 as multiplications
   unsigned long long seed;
   int picker_mode, start_lo, start_hi, env_id_offset;
   int sched_n;
@@ -202,9 +203,9 @@ struct FleetDev {
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
-  // auxiliary observation slots (observer_*.py:85-91, oracle_normalization.py:127-131), computed per lane from the carried
-  // schedule record: hn_scale = nominal capacity / (evse * eta_c), and the normaliser's reciprocals (1.0 when not normalising)
-  double hn_scale, inv_max_soc, inv_max_hours_needed, inv_max_laxity;
+  // auxiliary observation slots (observer_*.py:85-91), computed per lane from the carried schedule record:
+  // hn_scale = nominal capacity / (evse * eta_c); the normaliser's reciprocals are in FleetCold
+  double hn_scale;
   // ---- read-only tables ---------------------------------------------------------------------------------
   const SegRec* seg;          // [T,N] schedule records in run-length form
   const PhysRow* tab_phys;    // [T]
@@ -222,7 +223,8 @@ struct FleetDev {
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
   uint32_t* err_any;  // one word: OR of every FLEET_DEVERR_* bit any env has raised (lives in the block the host-pointer step copies
-                      // back with rewards and dones, so a failing step is reported by that very step at no extra cost)
+                      // back with rewards and dones, so a failing step is reported by that very step at no extra cost); the
+                      // kernels read the pointer from the device-resident copy of this block (`self`), on the error path only
   // device-side data log (FleetParams.log_data; utils/data_logger/data_logger.py:21-68): a ring of `log_cap` rows per env,
   // written by the kernels in every mode (single step, K-step, policy rollout, reset); env e's next row goes to slot
   // log_pos[e] % log_cap.  All nullptr / 0 when log_data is off.
@@ -232,8 +234,9 @@ struct FleetDev {
   double* log_env;    // [log_cap][E][4] reward, cashflow, overload_amount, cum_soc_missing (:659-661)
   double* log_ev;     // [log_cap][E][4][N] action, (dis)charging energy (ev_charger.py:114,174), degradation, soh
   float* log_obs;     // [log_cap][E][obs_dim] the (normalised) observation of the row
-  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (4 doubles) followed by the reversal log, EV-major and
-                      // 128-byte aligned
+  double* rf_rows;    // [E*N][rf_row_stride] per-EV rainflow row: RfHdr (6 doubles) followed by the reversal stack, EV-major
+                      // and 128-byte aligned so that a push / cycle closure touches ONE cache line (accumulators, stack top
+                      // and the entries below it) instead of one line per field / stack level
   int rf_row_stride;  // doubles per row (multiple of 16)
 };
 

@@ -26,14 +26,14 @@
 // flags the state machine needs travel in the env head; the physics record of the time row and the pre-assembled auxiliary
 // observation slots are requested when the head arrives and consumed late (money terms, observation stores).
 //
-// Rainflow without a history replay.  The reference keeps every SOC sample and re-runs rainflow over the whole episode
-// history every simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in
-// HBM: closed-cycle count, sum of cycle means, stress sum of the closed cycles that fall into the reference's slice, the stack
-// of reversal points; slope sign and stack size in the hot record) and feeds it ONE reversal point at a time: the step that
-// finds a point appends it (one store), the next step counts it -- with the row requested as soon as the hot record says so,
-// a whole step ahead of its use.  On the daily 14:45 row the forced last point and the residual half cycles are evaluated on
-// a *virtual* copy of the stack (registers only), which reproduces the reference's full recount, including its cross-episode
-// bookkeeping (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
+// Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
+// simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in HBM:
+// closed-cycle count, sum of cycle means, the two newest stack entries, stress sum of the closed cycles that fall into the
+// reference's slice, reversal stack; slope sign and stack size in the hot record) and feeds it ONE sample per step; the row
+// is only touched by a step that pushes a reversal point, requested in the middle of the step and consumed at its end.  On the daily 14:45 row
+// the forced last point and the residual half cycles are evaluated on a *virtual* copy of the stack (registers
+// only), which reproduces the reference's full recount, including its cross-episode bookkeeping
+// (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
 #include "fleet_device.h"
 
 #ifdef FLEET_STAMPS
@@ -67,18 +67,16 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 
 namespace {
 
-// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The multi-step
-// kernel's wavefronts advance independently and are bound by their own dependent round trips, so what counts is that all of a
-// 4096-env batch's wavefronts are resident at once: four per SIMD (128 VGPRs) -- +21 % env-steps/s over three
-// (profiles/r03_experiments/ab_multiwaves.log).  With several EVs per lane it stays at two.
+// Minimum workgroups per CU the kernels are compiled for (= waves per SIMD; register budget 512 / this).  The single-step
+// kernel needs 97 VGPRs.  The multi-step kernel wants ~150; its wavefronts advance independently and are bound by their own
+// dependent round trips, so what counts is that all of a 4096-env batch's wavefronts are resident at once: it is compiled for
+// four per SIMD (128 VGPRs, a few dozen bytes of spills) -- +21 % env-steps/s over the three its natural register count
+// allows (profiles/r03_experiments/ab_multiwaves.log).  With several EVs per lane it stays at two.
 constexpr int kSingleWaves = 4, kMultiWaves = 4, kMultiWideWaves = 2;
 #ifndef FLEET_KBLOCK
 #define FLEET_KBLOCK 256  // (a macro only because the diagnostic stamp code above indexes its buffer with it)
 #endif
-constexpr int kBlock = FLEET_KBLOCK;
-#ifndef FLEET_SKIP_SAME_HOT
-#define FLEET_SKIP_SAME_HOT 1  // (round-4 A/B switch; to be fixed once measured)
-#endif  // threads per workgroup
+constexpr int kBlock = FLEET_KBLOCK;  // threads per workgroup
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront helpers
@@ -191,6 +189,13 @@ typedef float fleet_v4f __attribute__((ext_vector_type(4)));
 // Everything else is stored plain: write-through (`sc1`) and non-temporal state stores were measured on every class of store
 // and lose everywhere (profiles/r03_experiments/ab_stores.log).
 __device__ __forceinline__ void st_obs(float* p, float v) { __builtin_nontemporal_store(v, p); }
+template <typename T>
+__device__ __forceinline__ void st_rec16(T* p, const T& v) {  // a 16-byte record as ONE store
+  static_assert(sizeof(T) == 16, "16-byte record");
+  fleet_v4f w;
+  __builtin_memcpy(&w, &v, 16);
+  *reinterpret_cast<fleet_v4f*>(p) = w;
+}
 // base + 32-bit byte offset.  The offset is made opaque at every use: its 64-bit zero-extension must be formed in the basic
 // block of the access for the instruction selector to see "uniform base + 32-bit lane offset" (scalar-base addressing); a
 // zero-extension hoisted into an earlier block arrives as an anonymous 64-bit vector value and costs a 64-bit vector add.
@@ -205,6 +210,8 @@ __device__ __forceinline__ const T* at_off(const T* base, unsigned& byte_off) {
   asm volatile("" : "+v"(byte_off));
   return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+template <typename T>
+__device__ __forceinline__ void st_plain(T* p, const T& v) { *p = v; }
 __device__ __forceinline__ void st_obs_at(float* base, unsigned& byte_off, float v) { st_obs(at_off(base, byte_off), v); }
 
 // One EV of one env: the planes [E, N] are addressed as (plane + e * N) + c -- the first part is wave-uniform when a
@@ -251,11 +258,14 @@ __device__ __forceinline__ double rcp_newton(double x) {
 // Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the step
 // advanced to (quirk Q10): there | target_soc * there | charging_left | hours_needed | laxity (observer_bl_pv.py:85-91), each
 // divided by the normaliser's constant when normalize_in_env (oracle_normalization.py:127-131).  They are computed per lane
-// from the carried schedule record in float64 and rounded to float32 like the reference's; the two divisions by constants and
-// the normaliser's are multiplications by the correctly rounded reciprocal and `time_left / (hours_needed + 0.001)` uses
-// rcp_newton: <= 2 ulp of float64 before the rounding to float32, i.e. the float32 word is the reference's except when the
-// float64 value lies within 2e-16 relative of a rounding boundary (tests/test_hip_parity.py reports the exact-match
-// fraction; the north-star tolerance is 1e-5).  Round 3 read these four words from a [T, N] table: 16 bytes per EV and step.
+// from the carried schedule record in float64 and rounded to float32 like the reference's; `cl * cap / (evse * eta)` and the
+// normaliser's divisions are multiplications by the correctly rounded quotient / reciprocal and `time_left / (hours_needed +
+// 0.001)` uses rcp_newton: <= 2 ulp of float64 before the rounding to float32, i.e. the float32 word is the reference's
+// except when the float64 value lies within ~2e-16 relative of a rounding boundary (tests/test_hip_parity.py reports the
+// exact-match fraction; the north-star tolerance is 1e-5).  np.clip keeps a NaN laxity (0 * inf: hours_needed == -0.001 exactly
+// for an absent EV), min / max here return 0 for it.  Round 3 read these four words from a [T, N] table: 16 bytes per EV and
+// step, 7 of a wavefront's 44 line requests; the two float64 divisions that had made the per-lane form lose in round 3
+// (ab_seg3.log) are gone.
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, double tgt,
                                              const RowRec& tb) {
   const int N = d.N;
@@ -270,14 +280,14 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   const double tgt_th = tgt * th;
   const double cl = tgt_th - tb.sor;
   const double hn = cl * d.hn_scale;
-  double lax = ((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th;
-  lax = fmin(fmax(lax, 0.0), 5.0);  // np.clip(., 0, 5)
+  const double lax = fmin(fmax(((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th, 0.0), 5.0);  // np.clip(., 0, 5)
   st_obs_at(a, o4, (float)tb.there);
   if (d.normalize) {
-    st_obs_at(a + N, o4, (float)(tgt_th * d.inv_max_soc));
-    st_obs_at(a + 2 * N, o4, (float)(cl * d.inv_max_soc));
-    st_obs_at(a + 3 * N, o4, (float)(hn * d.inv_max_hours_needed));
-    st_obs_at(a + 4 * N, o4, (float)(lax * d.inv_max_laxity));
+    const FleetCold* cd = d.self->cold;
+    st_obs_at(a + N, o4, (float)(tgt_th * cd->inv_max_soc));
+    st_obs_at(a + 2 * N, o4, (float)(cl * cd->inv_max_soc));
+    st_obs_at(a + 3 * N, o4, (float)(hn * cd->inv_max_hours_needed));
+    st_obs_at(a + 4 * N, o4, (float)(lax * cd->inv_max_laxity));
   } else {
     st_obs_at(a + N, o4, (float)tgt_th);
     st_obs_at(a + 2 * N, o4, (float)cl);
@@ -372,118 +382,140 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
   return s_dod * s_soc * stress_temp;
 }
 
-// rainflow.reversals fed one sample per step: equal samples are skipped, and a strict sign change of the slope makes the
-// PREVIOUS sample a reversal point.  Returns whether `old_deg` is one; `sgn` (0 none yet, 1 up, 2 down) is updated.
-__device__ __forceinline__ bool rf_reversal(double old_deg, double soc_deg, int& sgn) {
-  const bool moved = (soc_deg != old_deg);
-  const int s_next = (soc_deg > old_deg) ? 1 : 2;
-  const bool rev = moved && (sgn != 0) && (sgn != s_next);
-  sgn = moved ? s_next : sgn;
-  return rev;
+// A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
+// three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
+// The stack of the EV always starts at slot 0 (`tail` = its size; when the three-point rule drops the FIRST point -- the
+// stack is exactly [a, b, p] then -- the survivor below the top is rewritten to slot 0, so no head index exists and the size
+// alone describes it).  Its newest entry lives in the row header only (s2; s1 caches the one below), the entries below it in
+// the stack words behind the header (struct RfHdr in fleet_device.h).
+// The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
+// state machine, knows the new sample and therefore whether a reversal point is pushed, and REQUESTS the EV's row (header
+// head, stack top, the two entries below the top two: three 16-byte loads of one cache line); `rf_finish`, after the
+// observation stores and the money terms, consumes it.  A step that pushes nothing -- three in four -- never touches the row.
+struct RfReq {
+  double p;        // the reversal point to push
+  RfAccHead acc;   // requested when a point is pushed
+  RfTop top;       // stack[tail-2], stack[tail-1]
+  double w0, w1;   // stack[tail-3], [tail-4] (before the push)
+  bool push;
+  bool win;        // w0 / w1 were requested (else the pops read the stack words)
+};
+// `early`: the row's header and the entries below the top two were already requested at the start of the EV's step (K steps
+// per launch: the same row lines serve all K steps of the launch from the cache, and a wavefront that advances on its own is
+// bound by its own dependent round trips, which this removes from every step that pushes).
+__device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int tail, RfReq& q) {
+  const double* row = rf_row_of(d, i);
+  q.acc = *reinterpret_cast<const RfAccHead*>(row);
+  q.top = *reinterpret_cast<const RfTop*>(row + 2);
+  // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
+  const double* w = rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 4));  // tail >= 1
+  q.w1 = w[0];
+  q.w0 = w[1];
+  q.win = true;
 }
-
-// ---- the rainflow count: deferred by one step ------------------------------------------------------------------------------
-// A step that finds a reversal point APPENDS it to the EV's log (one 8-byte store, nothing is read) and marks it pending in the
-// hot record.  The NEXT step of the EV pushes it through the three-point rule.  What that needs of the EV's row -- the
-// accumulators and the four stack entries below the point -- is known to be needed as soon as the hot record has arrived (the
-// pending bit), i.e. a whole step of arithmetic before it is consumed: the row's round trip is off the wavefront's path.
-// (Round 3 decided and requested in the same step: the request could only leave after the state machine, and a dependent round
-// trip of ~2.7 k cycles sat between it and the end of the step on every wavefront, profiles/r03_experiments/stamps_*.)
-// A point that closes no cycle is already where it belongs -- it IS the new top of the stack -- so the count of such a point
-// stores nothing at all.  On the daily row the pending point and the point of the step itself are both counted before the
-// evaluation, so the evaluation sees exactly the reference's cycle list.
-// (Counting lazily in larger batches -- every 8th row, or only on the daily row, in an LDS copy of the log -- was built and
-// measured this round: the total work is the same, but it falls on a few wavefronts, which then end the launch; DESIGN.md
-// section 9, profiles/r04_experiments/lazy_*.)
-__device__ __forceinline__ void rf_append(const FleetDev& d, const EvIx& i, double p, int& tail, uint32_t& err) {
-  if (tail >= d.stack_cap) {  // cannot happen (points <= samples < stack_cap); refuse instead of overrunning
+__device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
+                                         bool early = false) {
+  q.push = false;
+  q.p = old_deg;
+  // rainflow.reversals, one sample per step: equal samples are skipped, a strict slope sign change makes the previous
+  // sample a reversal point
+  if (soc_deg != old_deg) {
+    const int s_next = (soc_deg > old_deg) ? 1 : 2;
+    q.push = (sgn != 0 && sgn != s_next);
+    sgn = s_next;
+  }
+  if (q.push && !early) rf_request(d, i, tail, q);
+}
+// `top`: the stack top after the push (only written when a point was pushed)
+// `acc_out`: the accumulator head after the push (only written when the push closed a cycle)
+__device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAccHead& acc_out,
+                                          uint32_t& err) {
+  if (!q.push) return;
+  double* row = rf_row_of(d, i);
+  double* stk = row + RF_HDR_WORDS;
+  if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
-  *rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail)) = p;
-  tail += 1;
-}
-
-// What the count of the log's newest point needs: the accumulators and the five newest log entries.
-struct RfReq {
-  RfAcc acc;
-  double p, b, a, w0, w1;  // log[T-1] (the point), log[T-2], log[T-3], log[T-4], log[T-5]
-};
-__device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int T, RfReq& q) {
-  const double* row = rf_row_of(d, i);
-  const double* lg = row + RF_HDR_WORDS;
-  q.acc = *reinterpret_cast<const RfAcc*>(row);
-  q.p = lg[T - 1];  // T >= 2: a pending point sits on top of at least the episode's first sample
-  q.b = lg[T - 2];
-  q.a = lg[T >= 3 ? T - 3 : 0];  // (shallow stack: any entry of the row, the value is not used)
-  q.w0 = lg[T >= 4 ? T - 4 : 0];
-  q.w1 = lg[T >= 5 ? T - 5 : 0];
-}
-
-// The newest log entry log[T-1] = q.p goes through the three-point rule on top of the stack log[0 .. T-1) (rainflow.
-// extract_cycles, the `while len(points) >= 3` loop).  Returns the stack size afterwards (the point included).
-__device__ __forceinline__ int rf_count_one(const FleetDev& d, const EvIx& i, const RfReq& q, int T) {
   const double p = q.p;
-  double a = q.a, b = q.b;
-  int size = T;  // points [.., a, b, p]
-  if (!(size >= 3 && !(fabs(p - b) < fabs(b - a)))) return T;  // no cycle closes: the point stays where it is, on top
-  double* row = rf_row_of(d, i);
-  double* lg = row + RF_HDR_WORDS;
-  int nwin = size - 3 > 2 ? 2 : size - 3;  // entries below (a, b) that are in registers: w0 = log[T-4], w1 = log[T-5]
+  double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
+  const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
+  if (!closes) {
+    st_plain(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 1)), b);  // the displaced top joins the stack words; tail >= 1
+    tail += 1;
+    top.s1 = b;
+    top.s2 = p;
+    st_plain(reinterpret_cast<RfTop*>(row + 2), top);
+    return;
+  }
+  int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;  // entries below the top two that are in registers
+  const double w0 = q.w0, w1 = q.w1;
+  tail += 1;
   const int L = q.acc.rf_len;
   int nc = q.acc.nc;
-  double mean_sum = q.acc.mean_sum;
-  while (size >= 3) {
+  double mean_sum = q.acc.mean_sum, dcsum = 0.0;
+  bool has_csum = false;
+  while (tail >= 3) {
     const double X = fabs(p - b), Y = fabs(b - a);
     if (X < Y) break;
     if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
-      const double rng = fabs(a - b);
-      RfHdr* hd = reinterpret_cast<RfHdr*>(row);
-      hd->csum += cycle_stress(rng, 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.self->stress_temp);
-      if ((float)rng > hd->maxdod) hd->maxdod = (float)rng;  // ("DoD too large" :164-167 is raised when the slice is evaluated)
+      dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
+      has_csum = true;
     }
     mean_sum += 0.5 * (a + b);
     nc += 1;
-    if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> [b, p]
-      lg[0] = b;
-      size = 2;
-    } else {  // full cycle, drop its two points -> [.., p]
-      size -= 2;
-      b = (nwin >= 1) ? q.w0 : lg[size - 2];
-      if (size >= 3) a = (nwin >= 2) ? q.w1 : lg[size - 3];
+    if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
+      stk[0] = b;
+      tail = 2;
+    } else {  // full cycle, drop its two points -> stack = [..., p]: the stack words keep what they have, p lives in s2
+      tail -= 2;
+      if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
+      else b = stk[tail - 2];
+      if (tail >= 3) {
+        if (nwin >= 2) a = w1;                     // stack[tail-3]
+        else a = stk[tail - 3];
+      } else {
+        a = 0.0;
+      }
       nwin = 0;
     }
   }
-  lg[size - 1] = p;
-  RfAcc out;
+  RfAccHead out;
   out.mean_sum = mean_sum;
   out.nc = nc;
   out.rf_len = L;
-  *reinterpret_cast<RfAcc*>(row) = out;
-  return size;
+  top.s1 = b;  // stack[tail-2]
+  top.s2 = p;  // stack[tail-1]
+  acc_out = out;
+  st_plain(reinterpret_cast<RfAccHead*>(row), out);
+  st_plain(reinterpret_cast<RfTop*>(row + 2), top);
+  if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
 }
 
-// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212), every logged
-// reversal point counted: `v` = the sample just logged (rainflow.reversals always yields the last sample), `n` = number of logged
-// samples, the counted stack is log[0 .. sz).
-//   1. the forced last point and the residual half cycles are evaluated on a virtual copy of the stack (vt, vh, registers);
-//      the counted state is not modified by them;
-//   2. the SEI model, when the cycle list has grown beyond rainflow_length (:144).
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int sz, uint32_t& err, double dt_hours) {
+// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
+// `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
+// residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
+// is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
+// `top` / `have_top`: the stack top when this step's push has just written it (registers are newer than the row).
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int tail, const RfTop& top, bool have_top,
+                                             uint32_t& err, double dt_hours, int* new_len = nullptr) {
   const size_t i = ix.flat();
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  const double* lg = row + RF_HDR_WORDS;
+  const double* stk = row + RF_HDR_WORDS;
   // everything this needs from memory is requested up front (one round trip)
-  RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
+  const RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
   SeiRec sr = d.sei[i];
-  double b = lg[sz - 1];
-  double a = lg[sz >= 2 ? sz - 2 : 0];
-  const int L = hd.rf_len, nc = hd.nc;
+  const int L = hd.rf_len;
+  const int nc = hd.nc;
+  const double mean_sum0 = hd.mean_sum, csum0 = hd.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
   const double st = d.stress_temp;
-  FLEET_STAMP(11);
-  double max_dod = (double)hd.maxdod;  // over the closed cycles of the slice (rf_count_one; rounded to float32: the test is `> 5`)
+#ifdef FLEET_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FLEET_STAMP(11);  // records arrived
+
   int nv = 0;
-  double vmean = 0.0, vsum = 0.0, pend = 0.0;
+  double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
   bool has_pend = false;
   auto emit = [&](double x1, double x2, double count) {
     if (has_pend) vsum += pend;  // the previous cycle is not the last one
@@ -498,8 +530,9 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
     nv += 1;
   };
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
-    int vt = sz, vh = 0;
+    int vt = tail, vh = 0;
     int size = vt - vh + 1;
+    double a = have_top ? top.s1 : hd.s1, b = have_top ? top.s2 : hd.s2;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -510,45 +543,48 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
       } else {
         vt -= 2;
         size -= 2;
-        b = lg[vt - 1];
-        a = (size >= 3) ? lg[vt - 2] : 0.0;
+        b = stk[vt - 1];
+        a = (size >= 3) ? stk[vt - 2] : 0.0;
       }
     }
-    // remaining ranges are half cycles: log[vh .. vt) followed by the forced point
-    double prev = lg[vh];
+    // remaining ranges are half cycles: stack[vh..vt) followed by the forced point
+    double prev = (vt - vh >= 2) ? stk[vh] : b;
     for (int j = vh + 1; j < vt; ++j) {
-      const double cur = lg[j];
+      const double cur = (j == vt - 1) ? b : stk[j];
       emit(prev, cur, 0.5);
       prev = cur;
     }
-    emit(prev, v, 0.5);
+    emit(b, v, 0.5);
   }
 
-  FLEET_STAMP(12);
+  FLEET_STAMP(12);  // stack walked, cycle stresses evaluated
   double degradation = 0.0;
-  double sei_l = sr.sei_l;
+  double sei_l = sei_l0;
   const int len = nc + nv;
   if (len > 0 && len > L) {
     if (max_dod > 5.0) err |= FLEET_DEVERR_DOD_RANGE;
     const double battery_age = (double)(n - 1) * dt_hours * 3600.0;  // max(End) is always the last sample's index
-    const double mean_soc_cal = (hd.mean_sum + vmean) / (double)len;
-    const double fd_cyc = sr.fd_cyc + (hd.csum + vsum);
+    const double mean_soc_cal = (mean_sum0 + vmean) / (double)len;
+    const double fd_cyc = fd_cyc0 + (csum0 + vsum);
     const double fd_cal = (4.14E-10 * battery_age) * exp(1.04 * (mean_soc_cal - 0.5)) * st;
     const double fd = fd_cyc + fd_cal;
     const double alpha = 5.75E-2, beta = 121.0;
     sei_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
     if (sei_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
-    degradation = sei_l - sr.sei_l;
+    degradation = sei_l - sei_l0;
     sr.fd_cyc = fd_cyc;
     sr.fd_cal = fd_cal;
     sr.sei_l = sei_l;
-    hd.rf_len = len;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
-    hd.csum = 0.0;
-    hd.maxdod = 0.0f;
-    *reinterpret_cast<RfHdr*>(row) = hd;
+    RfAccHead out;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
+    out.mean_sum = mean_sum0;
+    out.nc = nc;
+    out.rf_len = len;
+    *reinterpret_cast<RfAccHead*>(row) = out;
+    reinterpret_cast<RfHdr*>(row)->csum = 0.0;
+    if (new_len) *new_len = len;
   }
-  FLEET_STAMP(13);
-  const double s = sr.sei_soh - degradation;
+  FLEET_STAMP(13);  // SEI model evaluated
+  const double s = sei_soh0 - degradation;
   sr.sei_soh = s;
   d.sei[i] = sr;
   if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
@@ -573,7 +609,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // The hot record of an EV whose soc / soc_deg / hours_left are given (struct Hot in fleet_device.h): the shared float64
 // field, the FROZEN / INPLANE flags, and the soc_deg plane entry in the one case that needs it.  `plane_has` = the
 // plane already holds this soc_deg (the EV was INPLANE before and soc_deg has not changed since).
-__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int pend, int sgn,
+__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int sgn,
                                           uint32_t there, bool t090, bool plane_has) {
   Hot h;
   h.hl = hl;
@@ -588,7 +624,7 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
       if (!plane_has) d.soc_deg[i.flat()] = soc_deg;
     }
   }
-  h.bits = HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090);
+  h.bits = HOT_PACK(tail, sgn, frozen, inplane, there, t090);
   return h;
 }
 
@@ -613,9 +649,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const EvIx ix = {(size_t)e * N, (unsigned)c};
     const size_t i = ix.flat();
     const SegRec s0 = d.seg[(size_t)start * N + c];
-    // the record the first step of the episode advances to (as one 16-byte word: a struct temporary that is only copied through
-    // stays a private-memory object, which the compiler then parks in the LDS)
-    const fleet_v4f s1 = *reinterpret_cast<const fleet_v4f*>(&d.seg[(size_t)next * N + c]);
+    const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
     const RowRec tb = seg_row(s0, start, d.dt);
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
@@ -627,18 +661,18 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, 0, tb.there, t090, false);  // rainflow: the log is [first sample], counted
-    *reinterpret_cast<fleet_v4f*>(&d.run[i]) = s1;
+    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
+    d.run[i] = s1;
     d.soh[i] = soh;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-      RfHdr hd = *reinterpret_cast<const RfHdr*>(row);  // rainflow_length survives
+      RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
+      RfHdr hd = *hp;  // rainflow_length survives
       hd.mean_sum = 0.0;
-      hd.nc = 0;
       hd.csum = 0.0;
-      hd.maxdod = 0.0f;
-      *reinterpret_cast<RfHdr*>(row) = hd;
-      row[RF_HDR_WORDS] = soc_deg;  // the log is [soc_deg]: the first sample is the first reversal point
+      hd.nc = 0;
+      hd.s1 = 0.0;
+      hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
+      *hp = hd;
     }
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
     if (log_on) {
@@ -671,7 +705,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     er->start_done = start;  // bit 31 (episode.done) cleared
     if (r.t_end > d.T - 1) {
       atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
-      atomicOr(d.err_any, FLEET_DEVERR_TABLE_END);
+      atomicOr(d.self->err_any, FLEET_DEVERR_TABLE_END);
     }
   }
 }
@@ -691,33 +725,27 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
-// The tail of an EV's step: the rainflow log (the count of the point the last step appended, the append of the point this step
-// found), the linear model's daily update, the data-log row, and the stores of the state records that changed.
-//   `pend`: the log's newest entry is pending, and `rq` holds what its count needs (requested when the hot record arrived);
-//   `sz_out` = entries of the log afterwards (on the daily row all of them counted).
-template <int DEG>
-__device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, bool rev,
-                                          const RfReq& rq, int tail, int pend, int sgn, double soc, double soc_deg, double old_deg, float hl,
-                                          uint32_t there1, bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a,
-                                          double en, bool logs, size_t lrow, const Hot& h_in, uint32_t& err, int& sz_out) {
+// The tail of an EV's step: the rainflow push (second half), the linear model's daily update, the data-log row, and the
+// stores of the state records that changed.
+template <int DEG, bool WIDE>
+__device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
+                                          int tail, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
+                                          bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
+                                          size_t lrow, const Hot& h_in, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail,
+                                          RfTop& sei_top, bool& sei_have_top, RfAccHead& acc_c, RfTop& top_c, bool carry) {
   double soh = soh0;
-  if (DEG == FLEET_DEG_RAINFLOW && env_ok) {
-    if (pend) tail = rf_count_one(d, i, rq, tail);
-    pend = 0;
-    if (rev) {
-      const int before = tail;
-      rf_append(d, i, old_deg, tail, err);
-      pend = tail - before;
-      if (deg_row && pend) {  // the daily evaluation below needs the point of this very step counted as well: a second, dependent
-        RfReq r2;             // round trip, on one step in 96
-        rf_request(*d.self, i, tail, r2);
-        tail = rf_count_one(*d.self, i, r2, tail);
-        pend = 0;
-      }
-    }
-  }
-  sz_out = tail;
+  RfTop top = top_c;
+  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, acc_c, err);
+  const bool pushed = rq.push;
+  if (carry && pushed) top_c = top;
   if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
+  if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {
+    sei_sample = soc_deg;
+    sei_soh = soh0;
+    sei_tail = tail;
+    sei_top = top;
+    sei_have_top = pushed || carry;
+  }
   if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
     double* lev = d.log_ev + lrow * 4 * N + c;
     lev[0] = a;
@@ -726,15 +754,15 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
     lev[3 * N] = soh;
   }
   FLEET_STAMP(5);
-  const Hot h_out = hot_encode(d, i, soc, soc_deg, hl, tail, pend, sgn, there1, t090, inplane);
   if (env_ok) {
     // soc_deg == soc whenever the EV has hours left; otherwise it keeps its previous value, which shares the record's float64
     // field with an empty slot's soc == 0.  An EV that is away and stays away leaves its record as it was: no store (what a
-    // launch leaves dirty in the L2 is written back before it ends).
+    // launch leaves dirty in the L2 is written back before it ends; a third of a caretaker fleet's EV-steps).
+    const Hot h_out = hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane);
     const bool same = (__double_as_longlong(h_out.x) == __double_as_longlong(h_in.x)) &&
                       (__float_as_uint(h_out.hl) == __float_as_uint(h_in.hl)) && (h_out.bits == h_in.bits);
-    if (!FLEET_SKIP_SAME_HOT || !same) *ev_at(d.hot, i) = h_out;
-    if (crosses) *ev_at(d.run, i) = nr;  // the next launch advances into another segment of the EV's schedule
+    if (!same) st_rec16(ev_at(d.hot, i), h_out);
+    if (crosses) st_rec16(ev_at(d.run, i), nr);  // the next launch advances into another segment of the EV's schedule
     if (DEG == FLEET_DEG_LINEAR && deg_row) *ev_at(d.soh, i) = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
   }
 }
@@ -836,10 +864,23 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
   const bool rt = MULTI && (d.real_time != 0);
-  // (K steps per launch: carrying the EV's state record, its state of health and the schedule record in registers over the
-  // K steps was measured and is NOT done: -14 % K-step rate -- the kernel is at the 128-register limit of four resident
-  // wavefronts per SIMD and those loads overlap with other wavefronts' arithmetic anyway;
+  // K steps per launch, one EV per lane: the head of the EV's rainflow row (closed-cycle count, sum of means, rainflow_length,
+  // the two newest stack entries) is read ONCE per launch and carried in registers over the K steps -- a push updates the
+  // registers and stores to the row, nothing re-reads it; the stack words are only read when a closure pops into them
+  constexpr bool kRfCarry = MULTI && !WIDE && DEG == FLEET_DEG_RAINFLOW;
+  // (Carrying the EV's state record, its state of health and the schedule record the same way was measured and is NOT done:
+  // -14 % K-step rate -- the kernel is at the 128-register limit of four resident wavefronts per SIMD, the six extra live
+  // registers spill, and those loads overlap with other wavefronts' arithmetic anyway;
   // profiles/r03_experiments/ab_stcarry.log.)
+  RfAccHead acc_c = {0.0, 0, 0};
+  RfTop top_c = {0.0, 0.0};
+  auto carry_load = [&]() {
+    const EvIx i0 = {(size_t)e * N, (unsigned)(g < N ? g : N - 1)};
+    const double* row = rf_row_of(d, i0);
+    acc_c = *reinterpret_cast<const RfAccHead*>(row);
+    top_c = *reinterpret_cast<const RfTop*>(row + 2);
+  };
+  if (kRfCarry) carry_load();
   double last_rew = 0.0;
   bool last_done = false;
   uint32_t head_after = 0;   // single step: FLEET_TFLAG_* of the row after the one the launch advances to
@@ -919,7 +960,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // what the daily SEI pass needs of the lane's EV, carried in registers when a lane owns one EV (no reload round trip for
     // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
     double sei_sample = 0.0, sei_soh = 0.0;
-    int sei_sz = 0;
+    int sei_tail = 0;
+    RfTop sei_top = {0.0, 0.0};
+    bool sei_have_top = false;
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     // Several EVs per lane, one step per launch (N > 64): the lane's NEXT EV's records are requested before the current EV is
     // worked on (software pipelining of the lane loop) -- otherwise every turn of the loop starts with a memory round trip
@@ -953,11 +996,16 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
       if (inplane) old_deg = d.soc_deg[i.flat()];
-      // rainflow: the count of a pending point is requested now and consumed at the end of the EV's step
-      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
-      const int pend = (DEG == FLEET_DEG_RAINFLOW && env_ok) ? HOT_PEND(hb.bits) : 0;
       RfReq rq;
-      if (pend) rf_request(d, i, tail, rq);
+      rq.push = false;
+      constexpr bool kRfEarly = MULTI && DEG == FLEET_DEG_RAINFLOW;
+      rq.win = false;
+      if (kRfCarry) {
+        rq.acc = acc_c;
+        rq.top = top_c;
+      } else if (kRfEarly && env_ok) {
+        rf_request(d, i, HOT_TAIL(hb.bits), rq);
+      }
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
@@ -1049,8 +1097,13 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       }
       if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
-      // ---- SOC log (:655): one sample per step; whether the previous sample was a reversal point of the rainflow count
-      const bool rev = (DEG == FLEET_DEG_RAINFLOW) && rf_reversal(old_deg, soc_deg, sgn);
+      // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
+      // here and consumed after the observation stores and the money terms
+      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+      // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
+      // stores would cost the multi-step kernel a resident wavefront per SIMD)
+      constexpr bool kSplitRf = !MULTI;
+      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
@@ -1068,14 +1121,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      int sz_out;
-      ev_finish<DEG>(d, i, c, N, env_ok, deg_row, dt_step, rev, rq, tail, pend, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane, crosses,
-                     nr, soh0, a, en, logs, lrow, hb, err, sz_out);
-      if (DEG == FLEET_DEG_RAINFLOW && !WIDE) {  // what the daily pass needs of the lane's EV stays in registers
-        sei_sample = soc_deg;
-        sei_soh = soh0;
-        sei_sz = sz_out;
-      }
+      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
+      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
+                           crosses, nr, soh0, a, en, logs, lrow, hb, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c,
+                           top_c, kRfCarry);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -1129,20 +1178,23 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // ---- daily SEI evaluation (:666-671) ---------------------------------------------------------------------
     // Runs in a second pass over the group's EVs, after the per-step arithmetic has retired, so that its temporaries
     // (transcendentals, accumulators) never coexist with the hot path's registers.  One step in 96, and wave-uniform for
-    // G == 64.  Every reversal point has been counted by the step (ev_finish).
+    // G == 64.
     if (DEG == FLEET_DEG_RAINFLOW && deg_row && env_ok) {
       for (int c = g; c < N; c += G) {
         const EvIx ix = {(size_t)e * N, (unsigned)c};
         const size_t i = ix.flat();
-        double soh_new = sei_soh;
-        if (WIDE) {  // several EVs per lane: re-read the few words from the records this lane has just stored
+        double deg, soh_new;
+        if (!WIDE) {
+          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
+                             kRfCarry ? &acc_c.rf_len : nullptr);
+          soh_new = sei_soh - deg;
+        } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
-          sei_sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
-          sei_sz = HOT_TAIL(hb.bits);
-          soh_new = d.soh[i];
+          const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
+          const RfTop none = {0.0, 0.0};
+          deg = sei_evaluate(*d.self, ix, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
+          soh_new = d.soh[i] - deg;
         }
-        const double deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_sz, err, dt_step);
-        soh_new -= deg;
         d.soh[i] = soh_new;
         if (logs) {
           double* lev = d.log_ev + lrow * 4 * N + c;
@@ -1167,6 +1219,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
         head_reset = true;
         if (env_ok) {
           reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
+          if (kRfCarry) carry_load();  // the reset rewrote the row's head (same lane, same addresses: program order holds)
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
           r.t_end = d.tab_finish ? d.tab_finish[r.t] : r.t + d.episode_steps;
@@ -1212,7 +1265,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   }
   if (err && env_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
     atomicOr(&d.env[e].err, err);
-    atomicOr(d.err_any, err);
+    atomicOr(d.self->err_any, err);
   }
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
