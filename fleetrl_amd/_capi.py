@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -195,6 +195,7 @@ def load_library():
     lib.fleet_get_dev.argtypes = [vp, C.c_int, vp]
     lib.fleet_get_dist_factor.argtypes = [vp, vp]
     lib.fleet_check_errors.argtypes = [vp]
+    lib.fleet_last_step_error_bits.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.fleet_timer_start.argtypes = [vp]
     lib.fleet_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_last_step_episodes.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_double)),
@@ -211,7 +212,7 @@ def load_library():
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
                  "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
-                 "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes"):
+                 "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -224,5 +225,5 @@ EXPORTED_SYMBOLS = (
     "fleet_set_night_policy", "fleet_reset_host",
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
-    "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes",
+    "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
 )

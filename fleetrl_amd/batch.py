@@ -64,8 +64,38 @@ class FleetBatch:
 
     # ------------------------------------------------------------------------------------------------------
     def _check(self, rc: int):
+        if rc == _capi.ERR_STATE:
+            self._raise_device_error()
         if rc != _capi.OK:
             raise FleetHipError(rc, self.lib.fleet_last_error(self.h).decode())
+
+    def _raise_device_error(self):
+        """Device error bits -> the exception the reference raises at that line inside step() (fleet_environment.py:610,
+        rainflow_sei_degradation.py:164-167,179-180,209-210); running off the table -- a KeyError of the reference's
+        `db.loc[...]` lookups -- becomes an IndexError that names the env and the row.  Every exception carries `.status`
+        (= ERR_STATE) and `.error_bits` and `.env`."""
+        msg = self.lib.fleet_last_error(self.h).decode()
+        bits_all = np.zeros(self.E, dtype=np.uint32)
+        rows = np.zeros(self.E, dtype=np.int32)
+        # (plain fleet_get calls: they cannot fail with ERR_STATE themselves)
+        if self.lib.fleet_get(self.h, _capi.FIELDS["error_bits"][0], bits_all.ctypes.data) != _capi.OK or \
+           self.lib.fleet_get(self.h, _capi.FIELDS["time_idx"][0], rows.ctypes.data) != _capi.OK or not bits_all.any():
+            raise FleetHipError(_capi.ERR_STATE, msg)
+        e = int(np.flatnonzero(bits_all)[0])
+        bits = int(bits_all[e])
+        where = f"env {e} (global env {e + int(self.params.env_id_offset)}), table row {int(rows[e])} of {int(self.params.table_rows)}"
+        if bits & _capi.DEVERR_OBS_FORMAT:
+            exc = TypeError("Observation format not recognized")
+        elif bits & _capi.DEVERR_DOD_RANGE:
+            exc = TypeError("DoD too large.")
+        elif bits & _capi.DEVERR_NEG_LIFE:
+            exc = TypeError("Life degradation is negative")
+        elif bits & _capi.DEVERR_SOH_MISMATCH:
+            exc = RuntimeError("Degradation calculation is not correct")
+        else:
+            exc = IndexError(f"the episode runs past the last table row: {where}")
+        exc.status, exc.error_bits, exc.env, exc.detail = _capi.ERR_STATE, bits, e, f"{where}: {msg}"
+        raise exc
 
     def close(self):
         if getattr(self, "h", None):
@@ -278,4 +308,13 @@ class FleetBatch:
         return out
 
     def check_errors(self):
+        """Raise if any env carries device error bits (see _raise_device_error); `step()` does this by itself."""
         self._check(self.lib.fleet_check_errors(self.h))
+
+    def last_step_error_bits(self) -> int:
+        """OR of all envs' device error bits as of the last `step()` (already on the host)."""
+        out = C.c_uint32()
+        rc = self.lib.fleet_last_step_error_bits(self.h, C.byref(out))
+        if rc != _capi.OK:
+            raise FleetHipError(rc, self.lib.fleet_last_error(self.h).decode())
+        return int(out.value)

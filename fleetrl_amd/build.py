@@ -39,17 +39,35 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
+def build_variant(out: str, extra_flags) -> str:
+    """Diagnostic builds (in-kernel stamps, experiments): the same sources with extra hipcc flags, written to `out` -- which
+    must not be the product library's path: a build with non-standard flags never carries the product's name."""
+    out = os.path.abspath(out)
+    if out == os.path.abspath(lib_path()):
+        raise ValueError("a variant build must not overwrite the product library " + lib_path())
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = [hipcc(), *FLAGS, *list(extra_flags), *[os.path.join(csrc, s) for s in SOURCES], "-o", out]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libfleet_hip.so if it is missing or older than its sources.  Safe under `torch.distributed.run`: the ranks
     serialise on a lock file, the first one compiles into a temporary file in the same directory and renames it into place
-    (a rank never maps a half-written library), the others find the fresh library when they get the lock."""
+    (a rank never maps a half-written library), the others find the fresh library when they get the lock.
+    The product library is always built with FLAGS and nothing else (no environment variable can change them; diagnostic
+    builds go through build_variant to a different file)."""
     import fcntl
     import tempfile
 
+    if os.environ.get("FLEET_EXTRA_HIPCC_FLAGS"):
+        raise RuntimeError("FLEET_EXTRA_HIPCC_FLAGS is no longer honoured: the product library is built with fleetrl_amd.build.FLAGS "
+                           "only; use fleetrl_amd.build.build_variant(out, flags) for a diagnostic build under another file name")
     if not force and not needs_build():
         return lib_path()
     csrc = os.path.join(_HERE, "csrc")
-    extra = os.environ.get("FLEET_EXTRA_HIPCC_FLAGS", "").split()  # diagnostics only (ablation builds)
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
@@ -57,7 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 return lib_path()
             fd, tmp = tempfile.mkstemp(prefix=".libfleet_hip.", suffix=".so.tmp", dir=_HERE)
             os.close(fd)
-            cmd = [hipcc(), *FLAGS, *extra, *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
+            cmd = [hipcc(), *FLAGS, *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 os.unlink(tmp)

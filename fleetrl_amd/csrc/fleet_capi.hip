@@ -43,6 +43,7 @@ struct Batch {
   void* pin_actions = nullptr;
   float* pin_term = nullptr;
   bool host_step_has_episodes = false;
+  uint32_t last_step_err = 0;  // OR of the device error bits as of the last fleet_step_host
   double* st_dist = nullptr;
   int32_t* dev_sched = nullptr;
   FleetCold cold_host{};
@@ -482,6 +483,17 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   return FLEET_OK;
 }
 
+// Name the first env that carries device error bits (the reference raises at the offending line: fleet_environment.py:610,
+// rainflow_sei_degradation.py:164-167,179-180,209-210; running off the table is a KeyError of its `db.loc[...]`).
+const char* deverr_names(uint32_t bits, char* buf, size_t n) {
+  snprintf(buf, n, "%s%s%s%s%s", (bits & FLEET_DEVERR_OBS_FORMAT) ? " observation format not recognized;" : "",
+           (bits & FLEET_DEVERR_NEG_LIFE) ? " life degradation is negative;" : "",
+           (bits & FLEET_DEVERR_SOH_MISMATCH) ? " degradation calculation is not correct;" : "",
+           (bits & FLEET_DEVERR_DOD_RANGE) ? " DoD too large;" : "",
+           (bits & FLEET_DEVERR_TABLE_END) ? " the episode runs past the last table row;" : "");
+  return buf;
+}
+
 void drop_graph(Batch* b) {
   if (b->graph_exec) {
     (void)hipGraphExecDestroy(b->graph_exec);
@@ -741,6 +753,7 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   memcpy(reward, h->pin_small, (size_t)E * 8);
   memcpy(done, h->pin_small + h->small_off_done, (size_t)E);
+  h->last_step_err = *reinterpret_cast<const uint32_t*>(h->pin_small + h->small_off_count + 4);  // came with the rewards
   if (terminal_obs) {
     // terminal observations only exist for the envs that finished in this step: only those rows cross PCIe; rows of envs
     // that did not finish are left untouched
@@ -752,6 +765,18 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
       for (int k = 0; k < n; ++k) memcpy(terminal_obs + (size_t)idx[k] * h->d.obs_dim, h->pin_term + (size_t)k * h->d.obs_dim, row);
     }
   }
+  // Device error bits raised by this step (or left by an earlier one: they are sticky) are reported by this very call, like the
+  // reference raises inside step(); the outputs above are complete.  No extra launch or transfer on the clean path.
+  if (h->last_step_err) {
+    (void)fleet_check_errors(h);  // names the env in fleet_last_error
+    return FLEET_ERR_STATE;
+  }
+  return FLEET_OK;
+}
+
+int fleet_last_step_error_bits(fleet_handle h, uint32_t* bits) {
+  if (!h || !bits) return FLEET_ERR_INVALID;
+  *bits = h->last_step_err;
   return FLEET_OK;
 }
 
@@ -884,8 +909,11 @@ int fleet_check_errors(fleet_handle h) {
   if (rc) return rc;
   for (int i = 0; i < h->d.E; ++i)
     if (e[i]) {
-      char buf[160];
-      snprintf(buf, sizeof buf, "device error bits 0x%x on env %d (see FLEET_DEVERR_* in fleet_hip.h)", e[i], i);
+      std::vector<int32_t> t(h->d.E);
+      (void)fleet_get(h, FLEET_F_TIME_IDX, t.data());
+      char names[200], buf[400];
+      snprintf(buf, sizeof buf, "device error bits 0x%x on env %d at table row %d of %d:%s (FLEET_DEVERR_* in fleet_hip.h)", e[i], i, t[i],
+               h->d.T, deverr_names(e[i], names, sizeof names));
       h->error = buf;
       return FLEET_ERR_STATE;
     }

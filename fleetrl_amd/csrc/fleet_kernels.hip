@@ -703,10 +703,8 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     er->ep_len = 0;
     er->penalty_record = 0.0;
     er->start_done = start;  // bit 31 (episode.done) cleared
-    if (r.t_end > d.T - 1) {
-      atomicOr(&er->err, FLEET_DEVERR_TABLE_END);
-      atomicOr(d.self->err_any, FLEET_DEVERR_TABLE_END);
-    }
+    // (an episode whose finish row lies beyond the table is legal until a step leaves the table: FLEET_DEVERR_TABLE_END is raised
+    // there, like the KeyError of the reference's `db.loc[...]`)
   }
 }
 

@@ -11,13 +11,13 @@ from __future__ import annotations
 import numpy as np
 
 from . import _capi
-from .vec_env import FleetCore
+from .vec_env import FleetCore, _SB3VecEnv
 
 __all__ = ["FleetMixedVecEnv"]
 
 
-class FleetMixedVecEnv:
-    """stable-baselines3 `VecEnv` duck type over several `FleetCore` groups.  `groups` = [(env_config, num_envs, kwargs)],
+class FleetMixedVecEnv(_SB3VecEnv):
+    """stable-baselines3 `VecEnv` (a subclass of it when SB3 is installed, see vec_env.py) over several `FleetCore` groups.  `groups` = [(env_config, num_envs, kwargs)],
     kwargs as for `FleetCore` (e.g. `tables=`); all groups must have the same number of EVs and observation layout.
     Env ids (and with them the Philox start-row streams) run through the groups in order."""
 
@@ -38,7 +38,12 @@ class FleetMixedVecEnv:
         if any(c.obs_dim != c0.obs_dim or c.num_cars != c0.num_cars for c in self.cores):
             raise ValueError("all groups need the same number of EVs and the same observation flags")
         self.obs_dim, self.num_cars = c0.obs_dim, c0.num_cars
-        self.observation_space, self.action_space = c0.single_observation_space, c0.single_action_space
+        if _SB3VecEnv is not object:
+            _SB3VecEnv.__init__(self, off, c0.single_observation_space, c0.single_action_space)
+        else:
+            self.observation_space, self.action_space = c0.single_observation_space, c0.single_action_space
+            self.render_mode = None
+            self.reset_infos = [{} for _ in range(off)]
         dev = torch.device("cuda", device)
         E, D, N = self.num_envs, self.obs_dim, self.num_cars
         self._obs = torch.zeros((E, D), device=dev, dtype=torch.float32)
@@ -46,7 +51,6 @@ class FleetMixedVecEnv:
         self._act = torch.zeros((E, N), device=dev, dtype=torch.float32)
         self._rew = torch.zeros(E, device=dev, dtype=torch.float64)
         self._done = torch.zeros(E, device=dev, dtype=torch.uint8)
-        self.reset_infos = [{} for _ in range(E)]
 
     def _slices(self):
         for core, off in zip(self.cores, self.offsets):
@@ -98,6 +102,25 @@ class FleetMixedVecEnv:
         for core in self.cores:
             out.extend(getattr(core, name)(*args, **kwargs))
         return out if indices is None else [out[i] for i in indices]
+
+    def get_attr(self, attr_name: str, indices=None):
+        c0 = self.cores[0]
+        per_env = {"num_cars": self.num_cars, "render_mode": None, "observation_space": c0.single_observation_space,
+                   "action_space": c0.single_action_space}
+        if attr_name not in per_env:
+            raise AttributeError(attr_name)
+        n = self.num_envs if indices is None else (1 if isinstance(indices, int) else len(list(indices)))
+        return [per_env[attr_name]] * n
+
+    def set_attr(self, attr_name: str, value, indices=None):
+        raise AttributeError(f"attribute {attr_name!r} cannot be set on the fused batch")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else (1 if isinstance(indices, int) else len(list(indices)))
+        return [False] * n
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs  # the reference ignores reset(seed=...) (quirk Q12)
 
     def close(self):
         for core in self.cores:

@@ -32,6 +32,23 @@ from .spaces import Box, observation_bounds
 
 __all__ = ["FleetCore", "FleetVecEnv", "FleetVectorEnv", "FleetEnv"]
 
+# The reference's class IS a `gymnasium.Env` (fleet_environment.py:50) and is multiplied by an SB3 `VecEnv` (requirements.txt:
+# gymnasium==0.29.1, stable-baselines3==2.3.2).  SB3 and gymnasium test with isinstance (`BaseAlgorithm._wrap_env`,
+# `check_env`, `Monitor`), so when those packages are installed the classes below derive from their base classes; without them
+# (this build image) they are plain classes with the same surface.
+try:
+    import gymnasium as _gym
+
+    _GymEnv = _gym.Env
+    _GymVectorEnv = getattr(getattr(_gym, "vector", None), "VectorEnv", object)
+except ImportError:  # pragma: no cover - depends on the installation
+    _GymEnv = object
+    _GymVectorEnv = object
+try:
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
+except ImportError:  # pragma: no cover
+    _SB3VecEnv = object
+
 
 class FleetCore:
     """Shared engine: config -> tables -> params -> FleetBatch, plus the reference's getters."""
@@ -158,22 +175,27 @@ class FleetCore:
         self.batch.close()
 
 
-class FleetVecEnv:
-    """stable-baselines3 `VecEnv` duck type over one fused GPU batch."""
+class FleetVecEnv(_SB3VecEnv):
+    """stable-baselines3 `VecEnv` over one fused GPU batch: a subclass of `stable_baselines3.common.vec_env.VecEnv` when SB3 is
+    installed (every abstract method of SB3 2.3.2 is implemented: reset, step_async, step_wait, close, get_attr, set_attr,
+    env_method, env_is_wrapped), the same duck type without it."""
 
     def __init__(self, env_config, num_envs: int, **kw):
         # copy_obs=True: step() returns a fresh observation array like SubprocVecEnv does; False: the pinned transfer buffer
         # itself (overwritten four steps later; saves a 4 * num_envs * obs_dim byte host copy per step, see FleetBatch.step)
         self.copy_obs = bool(kw.pop("copy_obs", True))
         self.core = FleetCore(env_config, num_envs, auto_reset=True, **kw)
-        self.num_envs = self.core.num_envs
-        self.observation_space = self.core.single_observation_space
-        self.action_space = self.core.single_action_space
-        self.render_mode = None
-        self.metadata = {"render_modes": []}
         self._actions = None
         self._any_override = False
-        self.reset_infos = [{} for _ in range(self.num_envs)]
+        if _SB3VecEnv is not object:  # sets num_envs / spaces / reset_infos / _seeds / _options and asks get_attr("render_mode")
+            _SB3VecEnv.__init__(self, self.core.num_envs, self.core.single_observation_space, self.core.single_action_space)
+        else:
+            self.num_envs = self.core.num_envs
+            self.observation_space = self.core.single_observation_space
+            self.action_space = self.core.single_action_space
+            self.render_mode = None
+            self.metadata = {"render_modes": []}
+            self.reset_infos = [{} for _ in range(self.num_envs)]
 
     def reset(self):
         self.core.clear_start_overrides()
@@ -227,7 +249,7 @@ class FleetVecEnv:
     def get_attr(self, attr_name: str, indices=None):
         idx = self._indices(indices)
         per_env = {"num_cars": self.core.num_cars, "env_config": self.core.env_config, "render_mode": None,
-                   "observation_space": self.observation_space, "action_space": self.action_space}
+                   "observation_space": self.core.single_observation_space, "action_space": self.core.single_action_space}
         if attr_name not in per_env:
             raise AttributeError(attr_name)
         return [per_env[attr_name] for _ in idx]
@@ -277,12 +299,18 @@ class FleetVecEnv:
         return obs, rew, done
 
 
-class FleetVectorEnv:
-    """gymnasium vector-env signature (what RLlib / CleanRL style loops expect)."""
+class FleetVectorEnv(_GymVectorEnv):
+    """gymnasium vector-env signature (what RLlib / CleanRL style loops expect); a subclass of `gymnasium.vector.VectorEnv`
+    when gymnasium is installed."""
 
     def __init__(self, env_config, num_envs: int, **kw):
         self.copy_obs = bool(kw.pop("copy_obs", True))  # see FleetVecEnv
         self.core = FleetCore(env_config, num_envs, auto_reset=True, **kw)
+        if _GymVectorEnv is not object:
+            try:  # gymnasium 0.29: VectorEnv(num_envs, observation_space, action_space); 1.x: no arguments
+                _GymVectorEnv.__init__(self, self.core.num_envs, self.core.single_observation_space, self.core.single_action_space)
+            except TypeError:
+                _GymVectorEnv.__init__(self)
         self.num_envs = self.core.num_envs
         self.single_observation_space = self.core.single_observation_space
         self.single_action_space = self.core.single_action_space
@@ -295,7 +323,7 @@ class FleetVectorEnv:
         return self.core.batch.reset(), {}
 
     def step(self, actions):
-        obs, rew, done, term = self.core.batch.step(np.asarray(actions).reshape(self.num_envs, -1), copy=self.copy_obs)
+        obs, rew, done, term = self.core.batch.step(np.asarray(actions).reshape(self.core.num_envs, -1), copy=self.copy_obs)
         terminated = done.astype(bool)
         truncated = np.zeros(self.num_envs, dtype=bool)  # the reference always returns truncated=False (:702)
         infos = {}
@@ -306,12 +334,14 @@ class FleetVectorEnv:
             infos = {"final_observation": final, "_final_observation": terminated.copy()}
         return obs, rew, terminated, truncated, infos
 
-    def close(self):
+    def close(self, **kwargs):
         self.core.close()
+        self.closed = True
 
 
-class FleetEnv:
-    """Single environment with the reference's exact call signatures (gymnasium.Env protocol, no auto-reset)."""
+class FleetEnv(_GymEnv):
+    """Single environment with the reference's exact call signatures (`class FleetEnv(gym.Env)`, fleet_environment.py:50: a
+    subclass of `gymnasium.Env` when gymnasium is installed; no auto-reset)."""
 
     metadata = {"render_modes": ["human"]}
 

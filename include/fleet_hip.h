@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 5
+#define FLEET_ABI_VERSION 6
 
 /* status codes */
 #define FLEET_OK 0
@@ -285,8 +285,17 @@ int fleet_log_dropped(fleet_handle h, int64_t* rows);
 int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs);
 int fleet_log_clear(fleet_handle h);     /* forget all rows (asynchronous on the handle's stream) */
 
-/* raise FLEET_ERR_STATE if any env has device error bits set */
+/* Device-side errors -- the conditions under which the reference raises inside step(): `TypeError("Observation format not
+ * recognized")` fleet_environment.py:610, `TypeError("DoD too large.")` / `TypeError("Life degradation is negative")` /
+ * `RuntimeError("Degradation calculation is not correct")` rainflow_sei_degradation.py:164-167,179-180,209-210, and a table
+ * lookup past the last row -- set FLEET_DEVERR_* bits per env (sticky).
+ *   - fleet_step_host returns FLEET_ERR_STATE from the very call whose step raised them (its outputs are still complete): the OR
+ *     of all bits travels in the block that brings rewards and dones back, no extra launch or transfer.
+ *   - the *_dev entry points are asynchronous: poll with fleet_check_errors (one small launch + copy). */
+/* FLEET_ERR_STATE if any env has device error bits set; fleet_last_error names the first such env, its table row and the bits */
 int fleet_check_errors(fleet_handle h);
+/* the OR of all envs' error bits as of the last fleet_step_host (no device work) */
+int fleet_last_step_error_bits(fleet_handle h, uint32_t* bits);
 
 /* ---- measurement helpers (bench.py): HIP events on the handle's stream ------------------------------- */
 int fleet_timer_start(fleet_handle h);

@@ -71,7 +71,7 @@ def replay(g, engine, *, float_rtol=1e-9, obs_exact=True, check_sei=True, env_ma
     Ee = engine.E
     env_map = np.arange(Ee) % g.E if env_map is None else np.asarray(env_map)
     engine.set_start_schedule(g.starts[:, env_map])
-    worst = dict(obs=0.0, reward=0.0, soc=0.0, soh=0.0, cashflow=0.0)
+    worst = dict(obs=0.0, reward=0.0, soc=0.0, soh=0.0, cashflow=0.0, obs_words=0, obs_words_exact=0)
     obs = engine.reset()
     np.testing.assert_array_equal(engine.get("start_idx"), g.starts[0, env_map])
 
@@ -81,6 +81,9 @@ def replay(g, engine, *, float_rtol=1e-9, obs_exact=True, check_sei=True, env_ma
         else:
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=what)
         worst["obs"] = max(worst["obs"], rel_err(got, want))
+        worst["obs_words"] += int(np.size(want))  # how many float32 observation words are the reference's, bit for bit
+        worst["obs_words_exact"] += int(np.count_nonzero(np.asarray(got, dtype=np.float32).view(np.uint32) ==
+                                                         np.asarray(want, dtype=np.float32).view(np.uint32)))
 
     cmp_obs(obs, g.reset_obs[env_map, 0], "reset obs, episode 0")
     np.testing.assert_allclose(engine.get("soc"), g.reset_soc[env_map, 0], rtol=float_rtol, atol=0)

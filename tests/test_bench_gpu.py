@@ -81,3 +81,18 @@ def test_bench_rccl_branch_with_one_rank():
     assert res.returncode == 0, res.stderr[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["episodes_gathered"] == 512
+
+
+def test_bench_eight_ranks_on_one_gpu_over_gloo():
+    """The driver's 8-GPU run executes `shard_range`, env-id offsets, the build lock and the gather of eight shards for the first
+    time; here the same control flow with eight ranks sharing the one GPU (gloo: RCCL refuses several ranks per device), as
+    plain `python bench.py --gpus 8` (self-launch) on BASELINE configs[3]'s fleet type: every rank's finished episodes arrive."""
+    cmd = [sys.executable, "bench.py", "--gpus", "8", "--config", "c4", "--steps", "260", "--warmup", "20", "--envs-per-gpu", "256",
+           "--backend", "gloo", "--device-index", "0", "--prime-ms", "20", "--reps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 8 and d["collective_backend"] == "gloo" and d["config"]["envs_per_gpu"] == 256
+    assert d["episodes_gathered"] == 8 * 256
+    assert abs(d["value"] - 8 * 256 * 260 / (d["ms_per_step"] * 260 * 1e-3)) / d["value"] < 1e-9  # whole-job aggregate

@@ -132,14 +132,87 @@ def test_error_reporting():
         b.step(np.zeros((b.E + 1, g.N), dtype=np.float32))
     with pytest.raises(KeyError):
         b.get("no_such_field")
-    # an episode that would run past the table raises the device error word instead of reading out of bounds
-    b.set_start_schedule(np.full((1, b.E), g.tables.T - 10, dtype=np.int32))
+    # an episode that runs past the table raises the device error word instead of reading out of bounds -- at the step that leaves
+    # the table, like the reference's table lookup (a reset near the end of the table is legal)
+    b.set_start_schedule(np.full((1, b.E), g.tables.T - 3, dtype=np.int32))
     b.reset()
-    with pytest.raises(FleetHipError) as ei:
+    b.check_errors()
+    act = np.zeros((b.E, g.N), dtype=np.float32)
+    b.step(act)
+    b.step(act)
+    with pytest.raises(IndexError):
+        b.step(act)
+    with pytest.raises(IndexError) as ei:   # (the reference: a KeyError of its table lookup; here the env and the row are named)
         b.check_errors()
-    assert ei.value.status == _capi.ERR_STATE
+    assert ei.value.status == _capi.ERR_STATE and ei.value.error_bits & _capi.DEVERR_TABLE_END and "table row" in str(ei.value)
     assert (b.get("error_bits") & _capi.DEVERR_TABLE_END).all()
     b.close()
+
+
+def test_device_errors_are_raised_by_the_step_that_causes_them():
+    """The reference raises inside step() (fleet_environment.py:610, rainflow_sei_degradation.py:164-167,179-180,209-210, a
+    table lookup past the last row).  Here the kernels set per-env error bits, the host-pointer step brings their OR back in the
+    block that carries rewards and dones (no extra launch), fleet_step_host returns FLEET_ERR_STATE from that very call and
+    FleetBatch.step raises the reference's exception type: (a) an episode that runs off the table -> IndexError naming env and row,
+    on the step that leaves the table, not earlier; (b) a SOC series whose first half cycle is deeper than 5 -> TypeError("DoD too
+    large.") on the daily row that evaluates it, and the CPU oracle flags the same bit on the same step."""
+    from fleetrl_amd.batch import FleetBatch
+    from fleetrl_amd.config import resolve_config
+    from fleetrl_amd.params import make_params, time_features
+    from fleetrl_amd.synth import synth_tables
+    from oracle.fleet_oracle import OracleBatch
+    from test_rainflow_adversarial_gpu import _always_there_tables, _cfg
+
+    # (a) table end: one env starts 5 rows before the end of the table, the others far from it
+    g = load_trace("lmd1_price_linear")
+    p = params_for(g, num_envs=4)
+    b = FleetBatch(p, g.tables, g.time_feat)
+    starts = np.full((1, 4), 100, dtype=np.int32)
+    starts[0, 2] = g.tables.T - 6
+    b.set_start_schedule(starts)
+    b.reset()
+    a = np.zeros((4, g.N), dtype=np.float32)
+    for s in range(5):       # rows T-5 .. T-1: still inside the table
+        b.step(a)
+        assert b.last_step_error_bits() == 0
+    with pytest.raises(IndexError) as ei:   # the sixth step would read row T
+        b.step(a)
+    assert b.last_step_error_bits() & _capi.DEVERR_TABLE_END
+    assert ei.value.env == 2 and ei.value.status == _capi.ERR_STATE and "env 2" in str(ei.value)
+    assert list(np.flatnonzero(b.get("error_bits"))) == [2]
+    b.close()
+
+    # (b) DoD > 5: every EV comes back with SOC_on_return = 6 (a hand-made table), is charged "down" to the target by the
+    # first step (the reference's min(need / eta, demand) with a negative need), discharged for a while and charged again:
+    # reversal points [6.0, ~0.6, last] -> the first half cycle has range 5.4 and lies in the evaluated slice of the first
+    # daily row (rainflow_length = 1)
+    N, E = 4, 3
+    tb = _always_there_tables(N)
+    tb.soc_on_return[:] = 6.0
+    rc = resolve_config(_cfg(48))
+    p = make_params(rc, tb, E, seed=5)
+    tf = time_features(tb)
+    hip, cpu = FleetBatch(p, tb, tf), OracleBatch(p, tb, tf)
+    daily = int(np.flatnonzero((tb.hour == 14) & (tb.minute == 45))[3])
+    st = np.full((1, E), daily - 12, dtype=np.int32)
+    for eng in (hip, cpu):
+        eng.set_start_schedule(st)
+    np.testing.assert_array_equal(hip.reset(), cpu.reset())
+    raised_at = None
+    for s in range(14):
+        act = np.full((E, N), 1.0 if s == 0 or s >= 6 else -0.5, dtype=np.float32)
+        cpu.step(act)
+        try:
+            hip.step(act)
+            assert not cpu.get("error_bits").any(), f"the oracle flags an error at step {s}, the HIP step did not raise"
+        except TypeError as exc:
+            assert str(exc) == "DoD too large." and exc.error_bits & _capi.DEVERR_DOD_RANGE
+            raised_at = s
+            break
+    assert raised_at == 11, raised_at      # the step that advances to the daily row
+    assert (cpu.get("error_bits") & _capi.DEVERR_DOD_RANGE).all()
+    hip.close()
+    cpu.close()
 
 
 def test_get_dev_matches_get():

@@ -233,3 +233,16 @@ def test_create_rejects_a_negative_log_capacity():
     p.log_data, p.log_capacity = 1, -5
     rc, msg = _create_status(p, g.tables, g.time_feat)
     assert rc == _capi.ERR_INVALID and "log_capacity" in msg
+
+
+def test_product_build_takes_no_flags_from_the_environment(monkeypatch, tmp_path):
+    """An environment variable must not be able to turn libfleet_hip.so into a diagnostic build with the product's file name
+    (VERDICT r3): build() refuses FLEET_EXTRA_HIPCC_FLAGS, and build_variant() refuses the product's path."""
+    from fleetrl_amd import build
+
+    monkeypatch.setenv("FLEET_EXTRA_HIPCC_FLAGS", "-DFLEET_STAMPS")
+    with pytest.raises(RuntimeError, match="no longer honoured"):
+        build.build(force=True)
+    monkeypatch.delenv("FLEET_EXTRA_HIPCC_FLAGS")
+    with pytest.raises(ValueError, match="must not overwrite"):
+        build.build_variant(build.lib_path(), ["-DFLEET_STAMPS"])

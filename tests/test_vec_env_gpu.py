@@ -278,3 +278,57 @@ def test_mixed_fleet_vec_env_equals_its_groups_stepped_separately():
     mixed.close()
     for s in singles:
         s.close()
+
+
+def test_drop_in_classes_under_installed_gymnasium_and_sb3_base_classes():
+    """With gymnasium / stable-baselines3 importable (stand-ins with the real base classes' constructors, tests/
+    test_base_classes.py) the three classes construct through their base classes' __init__ -- SB3's VecEnv asks
+    get_attr("render_mode") in there -- pass the isinstance tests SB3 and gymnasium apply, and step as before."""
+    import importlib
+    import sys
+
+    from test_base_classes import fake_modules
+
+    fakes = fake_modules()
+    saved = {k: sys.modules.get(k) for k in list(fakes) + ["fleetrl_amd.spaces", "fleetrl_amd.vec_env"]}
+    sys.modules.update(fakes)
+    try:
+        for name in ("fleetrl_amd.spaces", "fleetrl_amd.vec_env"):
+            sys.modules.pop(name, None)
+        ve = importlib.import_module("fleetrl_amd.vec_env")
+        gym, vec = fakes["gymnasium"], fakes["stable_baselines3.common.vec_env"]
+        g = load_trace("lmd1_price_linear")
+        kw = dict(tables=g.tables, extrema=g.extrema, start_range=(0, 0))
+        venv = ve.FleetVecEnv(g.cfg, 3, start_rows=np.repeat(g.starts[:, :1], 3, axis=1), **kw)
+        assert isinstance(venv, vec.VecEnv) and venv.num_envs == 3 and venv.render_mode is None and len(venv.reset_infos) == 3
+        assert isinstance(venv.observation_space, gym.spaces.Box) and isinstance(venv.action_space, gym.spaces.Box)
+        obs = venv.reset()
+        np.testing.assert_array_equal(obs[1], g.reset_obs[0, 0])
+        o, r, d, infos = venv.step(np.repeat(g.actions[0, :1], 3, axis=0))   # VecEnv.step of the base class: step_async + step_wait
+        np.testing.assert_allclose(o[2], g.obs[0, 0], rtol=1e-5, atol=1e-6)
+        assert r.dtype == np.float32 and d.dtype == bool and len(infos) == 3
+        venv.close()
+        env = ve.FleetEnv(g.cfg, start_rows=g.starts[:, :1], **kw)
+        assert isinstance(env, gym.Env)
+        ob, info = env.reset()
+        np.testing.assert_array_equal(ob, g.reset_obs[0, 0])
+        env.close()
+        vv = ve.FleetVectorEnv(g.cfg, 2, start_rows=np.repeat(g.starts[:, :1], 2, axis=1), **kw)
+        assert isinstance(vv, gym.vector.VectorEnv) and vv.num_envs == 2
+        ob, _ = vv.reset()
+        o, r, term, trunc, inf = vv.step(np.repeat(g.actions[0, :1], 2, axis=0))
+        assert term.dtype == bool and not trunc.any()
+        vv.close()
+        assert vv.closed
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        import fleetrl_amd
+
+        for attr in ("spaces", "vec_env"):
+            mod = sys.modules.get(f"fleetrl_amd.{attr}")
+            if mod is not None:
+                setattr(fleetrl_amd, attr, mod)

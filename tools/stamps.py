@@ -1,5 +1,6 @@
 """Diagnostic: where a wavefront of the step kernel spends its cycles (s_memtime stamps, FLEET_STAMPS build only).
-Run on the GPU box:  FLEET_EXTRA_HIPCC_FLAGS=-DFLEET_STAMPS python3 -c "from fleetrl_amd import build; build.build(force=True)"; python3 tools/stamps.py
+Build (build container): python3 -c "from fleetrl_amd import build; build.build_variant('ab_stamps/x.so', ['-DFLEET_STAMPS'])"; run on
+the GPU box: bash tools/r04_stamps.sh <tag> [E ...] (copies each ab_stamps/*.so over the library for the run and restores it)
 Read the SHARES, not the absolute run time (the stamps serialise the schedule)."""
 import ctypes as C
 import os
