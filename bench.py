@@ -94,9 +94,9 @@ def kernel_source_sha() -> str:
 
 def committed_traffic(config: str, envs: int, evs: int):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
-    profiles/r03_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
+    profiles/r04_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
     The counters need rocprofv3, so they cannot be read inside this run: the figure is looked up, and `traffic_source` says so."""
-    for name in (f"r03_traffic_{config}.json", f"r03_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
+    for name in (f"r04_traffic_{config}.json", f"r04_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -393,6 +393,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "reps": reps, "ms_per_step_min": min(walls) * 1e3 / args.steps, "ms_per_step_max": max(walls) * 1e3 / args.steps,
+            # how `ms_per_step` / `value` were taken (not comparable with rounds 1-2, which timed ONE region with a blocking sync)
+            "timing": f"median of {reps} back-to-back regions of exactly {args.steps} launches each, barrier + synchronize on both "
+                      "sides, the wait inside a region spins on hipStreamQuery",
+            "errcheck": check,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{E} envs x {N} EVs per GPU, {fleets} fleet{'s (one third each)' if len(groups) > 1 else ''}, "
@@ -430,18 +434,27 @@ def main():
         print(json.dumps(out))
 
 
-def host_path(g0, groups, budget_s: float = 1.5):
+def host_path(g0, groups, budget_s: float = 1.0):
     """The host-pointer path, PCIe both ways, as an SB3 loop sees it (never the headline value): `fleet_step_host` through
-    FleetBatch.step with NumPy buffers, bounded to about a second."""
+    FleetBatch.step with NumPy buffers, bounded to about a second per variant.  Primary figure: the DEFAULT of FleetBatch.step /
+    FleetVecEnv (`copy=True`: a private copy of the observations per step, like the reference's env returns); beside it
+    `copy=False` (the pinned transfer buffer itself is handed out)."""
     acts = g0.tape[:8].cpu().numpy()
-    g0.batch.step(acts[0], copy=False)
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        g0.batch.step(acts[n % 8], copy=False)  # the pinned transfer buffer itself (SB3 copies what it keeps)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"env_steps_per_s": g0.E * n / dt, "ms_per_step": dt * 1e3 / n, "envs": g0.E,
+
+    def run(copy):
+        g0.batch.step(acts[0], copy=copy)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s:
+            g0.batch.step(acts[n % 8], copy=copy)
+            n += 1
+        dt = time.perf_counter() - t0
+        return g0.E * n / dt, dt * 1e3 / n
+
+    v_copy, ms_copy = run(True)
+    v_pin, ms_pin = run(False)
+    return {"env_steps_per_s": v_copy, "ms_per_step": ms_copy, "envs": g0.E, "copy_obs": True,
+            "no_copy": {"env_steps_per_s": v_pin, "ms_per_step": ms_pin, "copy_obs": False},
             "what": "fleet_step_host: actions host->device, one launch, observations/rewards/dones device->host, synchronous"}
 
 

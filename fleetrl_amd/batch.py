@@ -20,8 +20,14 @@ __all__ = ["FleetBatch", "FleetHipError"]
 
 class _PinnedBuffer:
     """Owner of one `fleet_host_alloc` block.  The NumPy arrays handed out are views of a ctypes array that holds a
-    reference to this object, so the block is freed when the LAST view of it dies -- not when the batch is closed or
-    collected (an observation returned by step() stays valid for as long as the caller keeps it)."""
+    reference to this object, so the block outlives the batch for as long as any view of it lives (an observation returned by
+    step() stays valid for as long as the caller keeps it).
+    When the last view dies the block is only PARKED (`_dead`): `hipHostFree` synchronises the device, so it must not run from a
+    finaliser -- which may fire on any thread, in the middle of a timed region, or at interpreter shutdown after the HIP runtime
+    is gone.  Parked blocks are released by `drain()` on the caller's thread: at the next step() / pinned_array() / close() of
+    any batch."""
+
+    _dead: list = []   # (lib, address) of blocks whose views are all gone
 
     def __init__(self, lib, nbytes: int):
         out = C.c_void_p()
@@ -38,10 +44,17 @@ class _PinnedBuffer:
     def __del__(self):
         try:
             if self.address:
-                self._lib.fleet_host_free(C.c_void_p(self.address))
+                _PinnedBuffer._dead.append((self._lib, self.address))
                 self.address = 0
-        except Exception:
+        except Exception:  # interpreter shutdown: the process is going away with its pinned memory
             pass
+
+    @classmethod
+    def drain(cls):
+        """Free the parked blocks (called on the caller's thread, never from a finaliser)."""
+        while cls._dead:
+            lib, addr = cls._dead.pop()
+            lib.fleet_host_free(C.c_void_p(addr))
 
 
 class FleetBatch:
@@ -102,17 +115,21 @@ class FleetBatch:
             self.lib.fleet_destroy(self.h)
             self.h = None
         self._obs_ring = []  # the blocks themselves live as long as any view of them (see _PinnedBuffer)
+        _PinnedBuffer.drain()
 
     def pinned_array(self, shape, dtype=np.float32) -> np.ndarray:
         """A NumPy array in pinned (page-locked) host memory (`fleet_host_alloc`): the host entry points move such buffers
         over PCIe without staging.  The memory is freed when the last view of the array is gone (independent of this batch's
         lifetime)."""
+        _PinnedBuffer.drain()
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         return _PinnedBuffer(self.lib, n).array(shape, dtype)
 
     def __del__(self):
         try:
-            self.close()
+            if getattr(self, "h", None):   # (a finaliser: destroy the handle, leave parked pinned blocks to the next drain())
+                self.lib.fleet_destroy(self.h)
+                self.h = None
         except Exception:
             pass
 
@@ -215,8 +232,11 @@ class FleetBatch:
         copy of it, like the reference's env returns a fresh array every step.  `copy=False` returns the pinned buffer itself
         (no 4 * E * obs_dim byte copy on the host): it is overwritten OBS_RING calls later -- enough for an SB3 loop, which
         holds the previous observation while it steps and copies what it keeps; not for code that collects observations in a
-        list.  Either way the memory stays valid for as long as the returned array is referenced."""
+        list.  Either way the memory stays valid for as long as the returned array is referenced -- with `copy=False` that is
+        page-locked memory (E * obs_dim * 4 bytes per retained array), which stays pinned until the array is dropped."""
         a, dt = self._act(actions, (self.E, self.N))
+        if _PinnedBuffer._dead:
+            _PinnedBuffer.drain()
         if len(self._obs_ring) < self.OBS_RING:
             self._obs_ring.append(self.pinned_array((self.E, self.obs_dim)))
         obs = self._obs_ring[self._obs_next % len(self._obs_ring)]

@@ -262,9 +262,8 @@ __device__ __forceinline__ double rcp_newton(double x) {
 // normaliser's divisions are multiplications by the correctly rounded quotient / reciprocal and `time_left / (hours_needed +
 // 0.001)` uses rcp_newton: <= 2 ulp of float64 before the rounding to float32, i.e. the float32 word is the reference's
 // except when the float64 value lies within ~2e-16 relative of a rounding boundary (tests/test_hip_parity.py reports the
-// exact-match fraction; the north-star tolerance is 1e-5).  np.clip keeps a NaN laxity (0 * inf: hours_needed == -0.001 exactly
-// for an absent EV), min / max here return 0 for it.  Round 3 read these four words from a [T, N] table: 16 bytes per EV and
-// step, 7 of a wavefront's 44 line requests; the two float64 divisions that had made the per-lane form lose in round 3
+// exact-match fraction; the north-star tolerance is 1e-5).  Round 3 read these four words from a [T, N] table: 16 bytes per EV
+// and step, 7 of a wavefront's 44 line requests; the two float64 divisions that had made the per-lane form lose in round 3
 // (ab_seg3.log) are gone.
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, double tgt,
                                              const RowRec& tb) {
@@ -280,7 +279,8 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   const double tgt_th = tgt * th;
   const double cl = tgt_th - tb.sor;
   const double hn = cl * d.hn_scale;
-  const double lax = fmin(fmax(((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th, 0.0), 5.0);  // np.clip(., 0, 5)
+  double lax = ((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th;
+  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);  // np.clip(., 0, 5): keeps -0.0 (an absent EV) and NaN like numpy does
   st_obs_at(a, o4, (float)tb.there);
   if (d.normalize) {
     const FleetCold* cd = d.self->cold;

@@ -45,7 +45,7 @@ s = buf.reshape(4096, 16)[: min(E, 4096), :9].astype(np.int64)  # one row per wa
 valid = (s > 0).all(axis=1)
 s = s[valid]
 names = ["entry->env head ready", "stage-2 issue + hot loads ready", "charge + state machine", "observation stores",
-         "money terms", "log append + state stores", "reductions + leader", "SEI pass / reset", ]
+         "money terms + rainflow push", "state stores", "reductions + leader", "SEI pass / reset", ]
 d = np.diff(s, axis=1)
 print("cycles per segment, median over the wavefronts (last step of the run):")
 for k, n in enumerate(names):
