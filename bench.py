@@ -274,7 +274,9 @@ def main():
     N = args.evs or spec["evs"]
     # a graph replays tape_len launches; a run shorter than that replays a graph of its own length
     L = max(1, min(args.tape_len, args.steps))
-    use_graph = not args.no_graph
+    # launches go through a captured hipGraph of L steps; a run shorter than 64 steps launches eagerly (one graph launch costs
+    # about as much as six kernel launches on the host: 9.9 vs 9.65 us per step measured for the driver's 20-step regions)
+    use_graph = (not args.no_graph) and args.steps >= 64
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):
         lo, hi = shard_range(E, len(spec["groups"]), k)  # env groups in order: the first E % n groups hold one env more
@@ -326,16 +328,16 @@ def main():
         barrier()
         walls.append(time.perf_counter() - t0)
     # the kernels' own time (roofline): HIP events on the streams the kernels run on, around regions of the same K launches
-    # (kept out of the wall-clock regions: two more operations on each stream per region)
-    ev_regions = []
-    for _ in range(min(reps, 7)):
-        barrier()
-        for g in groups:
-            g.batch.timer_start()
-        run(args.steps)
-        for g in groups:
-            g.batch.timer_mark()
-        ev_regions.append([g.batch.timer_read() for g in groups])
+    # (kept out of the wall-clock regions: two more operations on each stream per region).  The regions are enqueued back to
+    # back, each between its own pair of events, and read afterwards: no host gap between them, so a short region measures the
+    # same running kernel as a long one (a 20-launch region behind a host synchronize starts on a chip that has idled)
+    n_ev = max(3, min(reps, 15))
+    barrier()
+    for g in groups:
+        g.batch.time_regions_begin(n_ev, args.steps, g.tape.data_ptr(), g.L, g.obs.data_ptr(), g.reward.data_ptr(), g.done.data_ptr(),
+                                   use_graph=use_graph)
+    per_group = [g.batch.time_regions_read() for g in groups]
+    ev_regions = [[float(pg[i]) for pg in per_group] for i in range(n_ev)]
     w = torch.tensor(walls, device=cdev, dtype=torch.float64)
     if launched:
         dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time

@@ -206,13 +206,16 @@ def load_library():
     lib.fleet_timer_read.argtypes = [vp, C.POINTER(C.c_float)]
     lib.fleet_run_tape_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
+    lib.fleet_time_regions_begin.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
+    lib.fleet_time_regions_read.argtypes = [vp, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_use_own_stream", "fleet_log_dropped",
                  "fleet_log_capacity", "fleet_log_read",
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
                  "fleet_reset_dev", "fleet_step_dev", "fleet_step_many_dev", "fleet_rollout_policy_dev", "fleet_set_night_policy",
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
                  "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
-                 "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits"):
+                 "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
+                 "fleet_time_regions_begin", "fleet_time_regions_read"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -226,4 +229,5 @@ EXPORTED_SYMBOLS = (
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
+    "fleet_time_regions_begin", "fleet_time_regions_read",
 )

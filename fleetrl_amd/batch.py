@@ -295,6 +295,19 @@ class FleetBatch:
                                                    reward_ptr, done_ptr, ms.ctypes.data))
         return ms
 
+    def time_regions_begin(self, regions: int, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
+                           use_graph: bool = True, act_dtype: int = _capi.ACT_F32):
+        """Enqueue `regions` event-bracketed regions of exactly `steps` launches each (asynchronous)."""
+        self._n_regions = int(regions)
+        self._check(self.lib.fleet_time_regions_begin(self.h, int(regions), int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
+                                                       reward_ptr, done_ptr, int(bool(use_graph))))
+
+    def time_regions_read(self) -> np.ndarray:
+        """Per-region device durations [ms] of the regions enqueued by time_regions_begin."""
+        ms = np.zeros(self._n_regions, dtype=np.float32)
+        self._check(self.lib.fleet_time_regions_read(self.h, ms.ctypes.data))
+        return ms
+
     def timer_start(self):
         self._check(self.lib.fleet_timer_start(self.h))
 

@@ -51,6 +51,7 @@ struct Batch {
   FleetDev* self_dev = nullptr;
   void* st_field = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::vector<hipEvent_t> region_events;  // fleet_time_regions_begin / _read
   // cached tape graph
   hipGraphExec_t graph_exec = nullptr;
   const void* graph_tape = nullptr;
@@ -542,6 +543,8 @@ int fleet_destroy(fleet_handle h) {
   for (void* ptr : {(void*)h->pin_small, h->pin_actions, (void*)h->pin_term})
     if (ptr) (void)hipHostFree(ptr);
   if (h->dev_sched) (void)hipFree(h->dev_sched);
+  for (auto& e : h->region_events)
+    if (e) (void)hipEventDestroy(e);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -994,6 +997,34 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   for (; i < steps; ++i)
     HIP_TRY(h, fleet_launch_step(h->d, base + (size_t)(i % tape_len) * row, act_dtype, 1, obs, reward, done, nullptr, nullptr,
                                  h->stream));
+  return FLEET_OK;
+}
+
+int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
+                              double* reward, uint8_t* done, int use_graph) {
+  if (!h || regions < 1 || regions > 256) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  for (auto& e : h->region_events)
+    if (e) (void)hipEventDestroy(e);
+  h->region_events.assign(2 * (size_t)regions, nullptr);
+  for (auto& e : h->region_events) HIP_TRY(h, hipEventCreate(&e));
+  for (int r = 0; r < regions; ++r) {
+    HIP_TRY(h, hipEventRecord(h->region_events[2 * r], h->stream));
+    const int rc = fleet_run_tape_dev(h, steps, tape, tape_len, act_dtype, obs, reward, done, use_graph);
+    if (rc != FLEET_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->region_events[2 * r + 1], h->stream));
+  }
+  return FLEET_OK;
+}
+
+int fleet_time_regions_read(fleet_handle h, float* region_ms) {
+  if (!h || !region_ms || h->region_events.empty()) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipEventSynchronize(h->region_events.back()));
+  for (size_t r = 0; r < h->region_events.size() / 2; ++r)
+    HIP_TRY(h, hipEventElapsedTime(&region_ms[r], h->region_events[2 * r], h->region_events[2 * r + 1]));
+  for (auto& e : h->region_events)
+    if (e) (void)hipEventDestroy(e);
+  h->region_events.clear();
   return FLEET_OK;
 }
 

@@ -309,6 +309,14 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
 
+/* `regions` timed regions of exactly `steps` launches each (as fleet_run_tape_dev), enqueued back to back on the handle's stream
+ * with a HIP event before and after each: the kernels' own time per region, without the host's gaps between regions.
+ * _begin only enqueues (several handles' streams can be filled before any is read); _read waits and returns the per-region
+ * device durations in milliseconds (HOST array [regions]). */
+int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype,
+                             float* obs, double* reward, uint8_t* done, int use_graph);
+int fleet_time_regions_read(fleet_handle h, float* region_ms);
+
 /* like fleet_run_tape_dev without a graph, but brackets EVERY launch with its own HIP event pair on the handle's
  * stream and returns the per-launch device durations in milliseconds (HOST array [steps]); synchronous. */
 int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,

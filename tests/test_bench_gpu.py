@@ -37,7 +37,7 @@ def test_bench_json_contract_single_gpu():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"] == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
     assert abs(d["value"] - 512 * 300 / (d["ms_per_step"] * 300 * 1e-3)) / d["value"] < 1e-9
-    assert d["config"]["launch"] == "hipGraph of 64 launches"
+    assert d["config"]["launch"] == "hipGraph of 64 launches" and "timing" in d and d["errcheck"] is True
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["episodes_gathered"] == 512
