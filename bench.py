@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with --device-index) only exists to smoke-test the multi-rank control "
                          "flow with several ranks on ONE GPU, which RCCL refuses")
+    ap.add_argument("--gather", default="torch", choices=["torch", "capi"],
+                    help="the logging all-gather: through torch.distributed (default), or as ONE ncclAllGather issued by the C ABI "
+                         "(fleet_gather_episode_stats_rccl; single fleet type, --backend nccl; falls back to torch on any error)")
     ap.add_argument("--device-index", type=int, default=None, help="GPU to use instead of LOCAL_RANK (test hook, see --backend)")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed clock-ramp replay before the warmup steps")
     ap.add_argument("--deg", default=None, choices=["none", "linear", "rainflow"],
@@ -353,7 +356,37 @@ def main():
         g.batch.get_dev("last_ep_len", ln[off:off + g.E].data_ptr())
         off += g.E
     sync()
-    r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
+    gather_how = "torch.distributed all_gather_into_tensor" if launched else None
+    r_all = n_all = None
+    if args.gather == "capi" and launched and args.backend == "nccl" and len(groups) == 1:
+        # the same gather without PyTorch's collectives: rank 0 makes the RCCL id, the launcher's store hands it round, every rank
+        # creates its communicator and the library issues one ncclAllGather on the handle's stream
+        try:
+            import ctypes as C
+
+            from fleetrl_amd import _capi
+
+            lib = groups[0].batch.lib
+            uid = (C.c_char * 128)()
+            if rank == 0 and lib.fleet_rccl_unique_id(uid) != _capi.OK:
+                raise RuntimeError(lib.fleet_last_error(None).decode())
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            comm = C.c_void_p()
+            if lib.fleet_rccl_comm_create(local_rank, world, rank, box[0], C.byref(comm)) != _capi.OK:
+                raise RuntimeError(lib.fleet_last_error(None).decode())
+            out = torch.zeros((world, 2, E), device=dev, dtype=torch.float64)
+            if lib.fleet_gather_episode_stats_rccl(groups[0].batch.h, comm, world, C.c_void_p(out.data_ptr())) != _capi.OK:
+                raise RuntimeError(lib.fleet_last_error(groups[0].batch.h).decode())
+            sync()
+            r_all, n_all = out[:, 0, :].reshape(-1), out[:, 1, :].reshape(-1).to(torch.int32)
+            lib.fleet_rccl_comm_destroy(comm)
+            gather_how = "fleet_gather_episode_stats_rccl: one ncclAllGather issued by the C ABI"
+        except Exception as exc:  # noqa: BLE001 - a logging path must not cost the run its result
+            gather_how = f"torch.distributed all_gather_into_tensor (the C-ABI gather failed: {exc})"
+            r_all = None
+    if r_all is None:
+        r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
     barrier()
     gather_ms = (time.perf_counter() - t1) * 1e3
     check = os.environ.get("FLEET_BENCH_NO_ERRCHECK") != "1"  # diagnostics only (tools/ab_noerr.sh: ablation builds)
@@ -420,7 +453,7 @@ def main():
             "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * many_reps / (many_ms * 1e-3),
                           "algorithmic_bytes_per_env_step": g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K,
                           "GBps": (g0.bytes_step - 4 * g0.batch.obs_dim * (K - 1) / K) * g0.E * K * many_reps / (many_ms * 1e-3) / 1e9},
-            "log_gather_ms": gather_ms, "collective_backend": (args.backend if launched else None),
+            "log_gather_ms": gather_ms, "collective_backend": (args.backend if launched else None), "log_gather": gather_how,
             "episodes_gathered": int((n_all > 0).sum().item()),
         }
         if not args.no_host_path and world == 1:

@@ -43,6 +43,7 @@ FIELDS = {
     "done": (17, np.uint8, False),
     "episodes": (18, np.int32, False),
     "penalty_record": (19, np.float64, False),
+    "last_ep_len_f64": (20, np.float64, False),
 }
 
 _I32_FIELDS = (
@@ -208,6 +209,10 @@ def load_library():
     lib.fleet_time_steps_dev.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, vp]
     lib.fleet_time_regions_begin.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, f32p, f64p, u8p, C.c_int]
     lib.fleet_time_regions_read.argtypes = [vp, vp]
+    lib.fleet_rccl_unique_id.argtypes = [vp]
+    lib.fleet_rccl_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.fleet_rccl_comm_destroy.argtypes = [vp]
+    lib.fleet_gather_episode_stats_rccl.argtypes = [vp, vp, C.c_int, vp]
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_use_own_stream", "fleet_log_dropped",
                  "fleet_log_capacity", "fleet_log_read",
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
@@ -215,7 +220,8 @@ def load_library():
                  "fleet_reset_host", "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
                  "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
                  "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
-                 "fleet_time_regions_begin", "fleet_time_regions_read"):
+                 "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
+                 "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -229,5 +235,6 @@ EXPORTED_SYMBOLS = (
     "fleet_step_host", "fleet_get", "fleet_get_dev", "fleet_get_dist_factor", "fleet_check_errors", "fleet_timer_start",
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
-    "fleet_time_regions_begin", "fleet_time_regions_read",
+    "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
+    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl",
 )

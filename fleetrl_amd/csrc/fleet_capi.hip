@@ -5,6 +5,9 @@
 // There is no CPU path in this library: without a HIP device fleet_create fails with FLEET_ERR_NODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened at run time (fleet_rccl_*), nothing links against it
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -477,7 +480,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   }
   if ((rc = dev_alloc(b, &b->st_mask, E))) return rc;
   if ((rc = dev_alloc(b, &b->st_dist, EN))) return rc;
-  if ((rc = dev_alloc(b, (char**)&b->st_field, EN * 8))) return rc;
+  if ((rc = dev_alloc(b, (char**)&b->st_field, (EN > 2 * (size_t)E ? EN : 2 * (size_t)E) * 8))) return rc;  // a field, or the [2, E] gather block
   // device-resident copy of the (now complete) argument block for the out-of-line rare paths (reset, daily degradation)
   HIP_TRY(b, hipMemcpyAsync(b->self_dev, &d, sizeof(FleetDev), hipMemcpyHostToDevice, b->stream));
   HIP_TRY(b, hipStreamSynchronize(b->stream));
@@ -493,6 +496,37 @@ const char* deverr_names(uint32_t bits, char* buf, size_t n) {
            (bits & FLEET_DEVERR_DOD_RANGE) ? " DoD too large;" : "",
            (bits & FLEET_DEVERR_TABLE_END) ? " the episode runs past the last table row;" : "");
   return buf;
+}
+
+// RCCL, bound at run time: a process that never gathers across GPUs does not need librccl, and a process that has PyTorch in
+// it gets the copy PyTorch has already mapped (same soname) instead of a second one.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.lib || !api.why.empty()) return api;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) {
+    api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+    return api;
+  }
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.why = "librccl lacks an expected symbol";
+  return api;
 }
 
 void drop_graph(Batch* b) {
@@ -815,6 +849,7 @@ static size_t field_bytes(const FleetDev& d, int field) {
     case FLEET_F_FD_CAL: case FLEET_F_SEI_L: bytes = EN * 8; break;
     case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: bytes = EN * 4; break;
     case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD:
+    case FLEET_F_LAST_EP_LEN_F64:
     bytes = E * 8; break;
     case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
     case FLEET_F_EPISODES: bytes = E * 4; break;
@@ -855,6 +890,62 @@ int fleet_get_dist_factor(fleet_handle h, double* out) {
   HIP_TRY(h, fleet_launch_dist_factor(h->d, h->st_dist, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out, h->st_dist, (size_t)h->d.E * h->d.N * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FLEET_OK;
+}
+
+int fleet_rccl_unique_id(void* id128) {
+  if (!id128) return FLEET_ERR_INVALID;
+  RcclApi& r = rccl();
+  if (!r.why.empty()) { g_create_error = r.why; return FLEET_ERR_HIP; }
+  static_assert(sizeof(ncclUniqueId) == FLEET_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (r.GetUniqueId(&id) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return FLEET_ERR_HIP; }
+  memcpy(id128, &id, sizeof id);
+  return FLEET_OK;
+}
+
+int fleet_rccl_comm_create(int device, int world_size, int rank, const void* id128, void** comm) {
+  if (!id128 || !comm || world_size < 1 || rank < 0 || rank >= world_size) return FLEET_ERR_INVALID;
+  RcclApi& r = rccl();
+  if (!r.why.empty()) { g_create_error = r.why; return FLEET_ERR_HIP; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return FLEET_ERR_HIP; }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclComm_t c = nullptr;
+  const ncclResult_t rc = r.CommInitRank(&c, world_size, id, rank);
+  if (rc != ncclSuccess) {
+    g_create_error = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed");
+    return FLEET_ERR_HIP;
+  }
+  *comm = c;
+  return FLEET_OK;
+}
+
+int fleet_rccl_comm_destroy(void* comm) {
+  if (!comm) return FLEET_OK;
+  RcclApi& r = rccl();
+  if (!r.why.empty()) return FLEET_ERR_HIP;
+  return r.CommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? FLEET_OK : FLEET_ERR_HIP;
+}
+
+int fleet_gather_episode_stats_rccl(fleet_handle h, void* comm, int world_size, double* out_dev) {
+  if (!h || !comm || world_size < 1 || !out_dev) {
+    if (h) h->error = "fleet_gather_episode_stats_rccl: bad argument";
+    return FLEET_ERR_INVALID;
+  }
+  RcclApi& r = rccl();
+  if (!r.why.empty()) { h->error = r.why; return FLEET_ERR_HIP; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t E = (size_t)h->d.E;
+  // [2, E] float64 in the handle's staging block: returns, then lengths (exact in float64)
+  double* send = static_cast<double*>(h->st_field);
+  HIP_TRY(h, fleet_launch_gather_field(h->d, FLEET_F_LAST_EP_RETURN, send, h->stream));
+  HIP_TRY(h, fleet_launch_gather_field(h->d, FLEET_F_LAST_EP_LEN_F64, send + E, h->stream));
+  const ncclResult_t rc = r.AllGather(send, out_dev, 2 * E, ncclDouble, static_cast<ncclComm_t>(comm), h->stream);
+  if (rc != ncclSuccess) {
+    h->error = std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(rc) : "failed");
+    return FLEET_ERR_HIP;
+  }
   return FLEET_OK;
 }
 

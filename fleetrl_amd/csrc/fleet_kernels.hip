@@ -1310,6 +1310,7 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env[i].ep_len; break;
     case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env[i].last_ep_return; break;
     case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env[i].last_ep_len; break;
+    case FLEET_F_LAST_EP_LEN_F64: ((double*)out)[i] = (double)d.env[i].last_ep_len; break;
     case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = d.env[i].err; break;
     case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)(d.env[i].start_done < 0); break;
     case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].h.episodes; break;

@@ -199,6 +199,7 @@ typedef struct FleetEnvBatch* fleet_handle;
 #define FLEET_F_DONE 17          /* u8  [E]   episode.done */
 #define FLEET_F_EPISODES 18      /* i32 [E]   finished-episode counter */
 #define FLEET_F_PENALTY_RECORD 19 /* f64 [E]  episode.penalty_record */
+#define FLEET_F_LAST_EP_LEN_F64 20 /* f64 [E] length of the last finished episode as float64 (fleet_get_dev / the RCCL gather) */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */
@@ -267,6 +268,22 @@ int fleet_get(fleet_handle h, int field, void* out_host);
 int fleet_get_dev(fleet_handle h, int field, void* out_dev);
 /* `FleetEnv.get_dist_factor` (:782-799): hours_needed / (hours_left + 0.001) from a fresh observation, f64 [E,N] */
 int fleet_get_dist_factor(fleet_handle h, double* out_host);
+/* ---- multi-GPU logging gather ---------------------------------------------------------------------
+ * Envs are independent: one process per GPU, each with a handle for its own contiguous env range (FleetParams.env_id_offset),
+ * nothing exchanged on the data path.  The one collective is the gather of the finished episodes' returns / lengths for
+ * logging -- ONE RCCL all-gather over xGMI, enqueued on the handle's stream, no PyTorch in the process needed (the Python
+ * package does the same through torch.distributed, fleetrl_amd/distributed.py).  librccl is opened at run time.
+ *   fleet_rccl_unique_id       rank 0 makes the 128-byte id; the caller's launcher hands it to the other ranks (file, env, MPI ...)
+ *   fleet_rccl_comm_create     every rank: ncclCommInitRank on `device`; *comm is an ncclComm_t
+ *   fleet_gather_episode_stats_rccl   out_dev: DEVICE f64 [world_size, 2, E]: per rank, last_ep_return[E] then last_ep_len[E]
+ *                              (as float64) of that rank's envs; every rank must have the same E.  Asynchronous on the
+ *                              handle's stream (fleet_synchronize before reading). */
+#define FLEET_RCCL_UNIQUE_ID_BYTES 128
+int fleet_rccl_unique_id(void* id128);
+int fleet_rccl_comm_create(int device, int world_size, int rank, const void* id128, void** comm);
+int fleet_rccl_comm_destroy(void* comm);
+int fleet_gather_episode_stats_rccl(fleet_handle h, void* comm, int world_size, double* out_dev);
+
 /* ---- device-side data log (FleetParams.log_data = 1) ---------------------------------------------------------------
  * What `FleetEnv.get_log()` (:741-748) returns is rebuilt from this ring: row k of env e (k counted since creation or the
  * last fleet_log_clear; the ring holds the last `capacity` of them, row k in slot k % capacity) is

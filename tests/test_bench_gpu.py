@@ -81,6 +81,11 @@ def test_bench_rccl_branch_with_one_rank():
     assert res.returncode == 0, res.stderr[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["episodes_gathered"] == 512
+    # ... and the same gather issued by the C ABI itself (one ncclAllGather on the handle's stream, --gather capi)
+    res = subprocess.run(cmd + ["--gather", "capi"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _json_line(res.stdout)
+    assert d["episodes_gathered"] == 512 and d["log_gather"].startswith("fleet_gather_episode_stats_rccl"), d["log_gather"]
 
 
 def test_bench_eight_ranks_on_one_gpu_over_gloo():

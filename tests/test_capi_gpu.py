@@ -284,3 +284,36 @@ def test_c_abi_from_plain_c(tmp_path):
     for v in hip.get("soc").reshape(-1).tolist():  # same left-to-right float64 sum as the C loop
         soc_sum += v
     assert c_soc == soc_sum
+
+
+def test_rccl_gather_of_episode_stats_through_the_c_abi():
+    """SURVEY.md section 8e / north star: "a single RCCL gather of episode returns for logging".  The C ABI does it without
+    PyTorch's collectives: fleet_rccl_unique_id / fleet_rccl_comm_create (ncclCommInitRank) / fleet_gather_episode_stats_rccl (one
+    ncclAllGather on the handle's stream).  The pool's boxes have one GPU, so the communicator has one rank here; the gathered
+    block must equal the handle's own last_ep_return / last_ep_len."""
+    import torch
+
+    from fleetrl_amd.batch import FleetBatch
+
+    g = load_trace("lmd1_price_linear")
+    E = 6
+    b = FleetBatch(params_for(g, num_envs=E), g.tables, g.time_feat)
+    b.set_start_schedule(np.repeat(g.starts[:, :1], E, axis=1))
+    b.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(g.ep_steps + 3):        # one finished episode per env
+        b.step(rng.uniform(-1, 1, size=(E, g.N)).astype(np.float32))
+    lib = b.lib
+    uid = (C.c_char * 128)()
+    assert lib.fleet_rccl_unique_id(uid) == _capi.OK, lib.fleet_last_error(None)
+    comm = C.c_void_p()
+    assert lib.fleet_rccl_comm_create(0, 1, 0, uid, C.byref(comm)) == _capi.OK, lib.fleet_last_error(None)
+    out = torch.zeros((1, 2, E), device="cuda:0", dtype=torch.float64)
+    assert lib.fleet_gather_episode_stats_rccl(b.h, comm, 1, C.c_void_p(out.data_ptr())) == _capi.OK, lib.fleet_last_error(b.h)
+    b.synchronize()
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[0, 0], b.get("last_ep_return"))
+    np.testing.assert_array_equal(got[0, 1], b.get("last_ep_len").astype(np.float64))
+    assert (got[0, 1] == g.ep_steps).all()
+    assert lib.fleet_rccl_comm_destroy(comm) == _capi.OK
+    b.close()
