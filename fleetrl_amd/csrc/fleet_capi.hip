@@ -120,7 +120,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     return "rainflow/SEI degradation needs init_soh == 1.0 (the reference's used-battery branch is ill-defined, quirk Q4)";
   // the rainflow stack size travels in a 26-bit field of the hot record (fleet_device.h HOT_PACK)
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->episode_steps > FLEET_MAX_STACK_ROWS - 3)
-    return "rainflow/SEI degradation: episode_steps exceeds 33 million (the packed size of the rainflow log is 25 bits wide)";
+    return "rainflow/SEI degradation: episode_steps exceeds 67 million (the packed rainflow stack size is 26 bits wide)";
   // ... and the kernels address an EV's rainflow row as (its env's rows) + a 32-bit byte offset
   if (p->deg_mode == FLEET_DEG_RAINFLOW && (uint64_t)p->num_cars * ((uint64_t)p->episode_steps + 24) * 8ull >= (1ull << 32))
     return "rainflow/SEI degradation: num_cars x episode_steps too large (the rainflow rows of one env exceed 4 GiB)";
@@ -129,7 +129,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
     for (int r = 0; r < p->table_rows; ++r) {
       if (t->finish_row[r] >= p->table_rows) return "finish_row entry outside the table";
       if (p->deg_mode == FLEET_DEG_RAINFLOW && t->finish_row[r] - r > FLEET_MAX_STACK_ROWS - 3)
-        return "rainflow/SEI degradation: an episode spans more than 33 million rows (the packed size of the rainflow log is 25 bits wide)";
+        return "rainflow/SEI degradation: an episode spans more than 67 million rows (the packed rainflow stack size is 26 bits wide)";
     }
   if (t->lookahead_row)
     for (size_t k = 0; k < (size_t)p->table_rows * (size_t)t->lookahead_cols; ++k)
@@ -440,18 +440,10 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
     h0.rf_len = 1;
-    h0.sz = h0.upto = 1;
     std::vector<RfHdr> hdrs(EN, h0);
     HIP_TRY(b, hipMemcpy2DAsync(d.rf_rows, (size_t)d.rf_row_stride * 8, hdrs.data(), sizeof(RfHdr), sizeof(RfHdr), EN,
                                 hipMemcpyHostToDevice, b->stream));
     HIP_TRY(b, hipStreamSynchronize(b->stream));
-    // one env per wavefront: the one-step-per-launch kernel hands the rainflow count to a helper wavefront (fleet_kernels.hip
-    // rf_helper); FLEET_RF_HELPER=0 keeps the count in the step (for A/B runs: the results are the same)
-    const char* ov = getenv("FLEET_RF_HELPER");
-    if (N > 32 && N <= 64 && !(ov && ov[0] == '0')) {
-      if ((rc = dev_alloc(b, &d.rf_snap, EN))) return rc;
-      if ((rc = dev_alloc(b, &d.rf_need, (size_t)E))) return rc;
-    }
   }
   {
     // persistent degradation state (RainflowSeiDegradation.__init__, rainflow_sei_degradation.py:24-66), the initial

@@ -81,23 +81,20 @@ __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
 struct Hot {
   double x;        // episode.soc and / or episode.soc_deg, see above
   float hl;        // episode.hours_left (multiple of dt, exact in f32)
-  uint32_t bits;   // [24:0] entries of the EV's rainflow log, [25] PENDING: some of them have not been counted yet (RfHdr.sz / .upto
-                   // say which), [26] INPLANE, [28:27] sign of the last SOC slope (0 none, 1 up, 2 down), [29] FROZEN,
-                   // [30] There at the current time row (carried so the step needs no table read for it), [31] sticky
-                   // "target_soc = 0.9" flag (quirk Q7)
+  uint32_t bits;   // [25:0] rainflow stack size (the stack always starts at slot 0), [26] INPLANE, [28:27] sign of the last
+                   // SOC slope (0 none, 1 up, 2 down), [29] FROZEN, [30] There at the current time row (carried so the
+                   // step needs no table read for it), [31] sticky "target_soc = 0.9" flag (quirk Q7)
 };
-#define HOT_TAIL(b) ((int)((b) & 0x1FFFFFFu))
-#define HOT_PEND(b) ((((b) >> 25) & 1u) != 0u)
+#define HOT_TAIL(b) ((int)((b) & 0x3FFFFFFu))
 #define HOT_INPLANE(b) ((((b) >> 26) & 1u) != 0u)
 #define HOT_SGN(b) ((int)(((b) >> 27) & 3u))
 #define HOT_FROZEN(b) ((((b) >> 29) & 1u) != 0u)
 #define HOT_THERE(b) (((b) >> 30) & 1u)
 #define HOT_T090(b) (((b) >> 31) != 0u)
-#define FLEET_MAX_STACK_ROWS 0x1FFFFFF  // 25-bit log size: 33 million samples per episode
-#define HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090)                                                            \
-  (((uint32_t)(tail) & 0x1FFFFFFu) | ((pend) ? 0x2000000u : 0u) | ((inplane) ? 0x4000000u : 0u) |                         \
-   (((uint32_t)(sgn) & 3u) << 27) | ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) |                    \
-   ((t090) ? 0x80000000u : 0u))
+#define FLEET_MAX_STACK_ROWS 0x3FFFFFF  // 26-bit stack size: 67 million samples per episode
+#define HOT_PACK(tail, sgn, frozen, inplane, there, t090)                                                                 \
+  (((uint32_t)(tail) & 0x3FFFFFFu) | ((inplane) ? 0x4000000u : 0u) | (((uint32_t)(sgn) & 3u) << 27) |                    \
+   ((frozen) ? 0x20000000u : 0u) | (((uint32_t)(there) & 1u) << 30) | ((t090) ? 0x80000000u : 0u))
 // episode.soc / episode.soc_deg of a hot record (`plane` = the EV's soc_deg plane entry, only read when INPLANE)
 #define HOT_SOC(h) ((HOT_FROZEN((h).bits) && !HOT_INPLANE((h).bits)) ? 0.0 : (h).x)
 
@@ -136,37 +133,34 @@ struct EnvRec {
 };
 static_assert(sizeof(EnvRec) == 64, "one 64-byte record per env");
 
-// Rainflow row of (env e, EV c), 128-byte aligned: a 48-byte header followed by the EV's log of reversal points.
-// The reference keeps every SOC sample of the episode and re-counts the cycles of the whole history on the daily 14:45 row
-// (rainflow.extract_cycles over LogDataDeg.soc_log, rainflow_sei_degradation.py:130-135); between two daily rows nothing of the
-// count is observable.  Three-point counting only ever looks at reversal points, in order, so the kernels keep the three-point
-// STACK (the points no closed cycle has consumed yet) and the accumulators over the closed cycles:
-//   Hot.bits PENDING clear:  log[0 .. tail) is the stack (every point counted)
-//   Hot.bits PENDING set:    log[0 .. sz) is the stack, log[sz .. upto) is dead, log[upto .. tail) are reversal points that were
-//                            appended (one 8-byte store, nothing read) and not counted yet; sz / upto live in the header
-// Counting is in place (the stack can never be longer than the number of points counted so far) and folds the accumulators in
-// the same order whenever it happens, so results do not depend on WHEN a point is counted -- only the daily row needs them all.
+// Rainflow row of (env e, EV c): a 48-byte header followed by the reversal stack, 128-byte aligned, so that everything a
+// push touches -- accumulators, the two newest stack entries, the entries right below them -- sits in ONE cache line for
+// the usual stack depths.  Nothing of it is read by a step that pushes no reversal point (three steps in four): whether
+// a step pushes is decided from the hot record alone (sign of the last slope), and only then is the row requested.
+//   * `s2` is the ONLY copy of the newest stack entry: the stack words hold the entries below it (stack[0 .. tail-2];
+//     `s1` caches the last of them).  A push that closes no cycle therefore writes one stack word (the displaced old
+//     top), and a push that closes a full cycle writes none (the two popped points vanish, the new point stays in s2).
+//   * what every closure reads and writes sits in the first 16 bytes, the stack top in the next 16.
 struct RfHdr {
   double mean_sum;  // sum of cycle means over the closed cycles of this episode
   int32_t nc;       // closed cycles this episode
-  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6: reset() keeps it)
-  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_push)
-  float maxdod;     // largest range among those cycles (the reference's "DoD too large" test, :164-167)
-  int32_t pad0;
-  int32_t sz;       // (PENDING) the stack is log[0 .. sz)
-  int32_t upto;     // (PENDING) log[upto .. tail) are the points not counted yet
-  double pad1;
+  int32_t rf_len;   // RainflowSeiDegradation.rainflow_length (persists across episodes, quirk Q6)
+  double s1;        // stack[tail-2]
+  double s2;        // stack[tail-1]
+  double csum;      // stress sum of the closed cycles with index >= rainflow_length-1 (rarely non-zero, see rf_finish)
+  double pad;
 };
-struct RfAcc {  // bytes 0..15 of RfHdr: what every closed cycle reads and writes
+struct RfAccHead {  // bytes 0..15 of RfHdr
   double mean_sum;
   int32_t nc;
   int32_t rf_len;
 };
-struct RfMark {  // bytes 32..39 of RfHdr
-  int32_t sz, upto;
+struct RfTop {  // bytes 16..31 of RfHdr
+  double s1;
+  double s2;
 };
-#define RF_HDR_WORDS 6  // doubles of the header; the log follows
-static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAcc) == 16 && sizeof(RfMark) == 8 && offsetof(RfHdr, sz) == 32, "RfHdr layout");
+#define RF_HDR_WORDS 6  // doubles of the header; the stack follows
+static_assert(sizeof(RfHdr) == 8 * RF_HDR_WORDS && sizeof(RfAccHead) == 16 && sizeof(RfTop) == 16, "RfHdr layout");
 // SEI model state of (env e, EV c), 32 B, touched on the daily row only (persists across episodes, quirk Q6).
 struct SeiRec {
   double fd_cyc;   // RainflowSeiDegradation.fd_cyc
@@ -228,13 +222,6 @@ struct FleetDev {
   double* soc_deg;    // [E,N] (valid where the INPLANE bit is set)
   SeiRec* sei;        // [E,N]
   EnvRec* env;        // [E]
-  // The rainflow count of a batch stepped one step per launch with one env per wavefront is done by a HELPER wavefront per
-  // workgroup (fleet_kernels.hip rf_helper), ahead of the daily row: `rf_snap[e, c]` = entries of the EV's log as of the end of
-  // the env's last step, `rf_need[e]` = launches the helper may still spend on env e (0: nothing to do).  Written by the env's
-  // own wavefront at the end of a launch, consumed by the helper in the next.  nullptr: no helper (every other kernel counts a
-  // reversal point in the step that finds it).
-  int32_t* rf_snap;   // [E,N]
-  int32_t* rf_need;   // [E]
   uint32_t* err_any;  // one word: OR of every FLEET_DEVERR_* bit any env has raised (lives in the block the host-pointer step copies
                       // back with rewards and dones, so a failing step is reported by that very step at no extra cost); the
                       // kernels read the pointer from the device-resident copy of this block (`self`), on the error path only

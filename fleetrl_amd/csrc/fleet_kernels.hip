@@ -382,35 +382,35 @@ __device__ __forceinline__ double cycle_stress(double rng, double mean, double c
   return s_dod * s_soc * stress_temp;
 }
 
-// A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the three-point rule allows
-// (rainflow.extract_cycles, the `while len(points) >= 3` loop).  The stack is log[0 .. tail) in the EV's row (struct RfHdr in
-// fleet_device.h); when the rule drops the FIRST point -- the stack is exactly [a, b, p] then -- the survivor is rewritten to
-// slot 0, so no head index exists and the size alone describes it.
-// The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the state
-// machine, knows the new sample and therefore whether a reversal point is pushed, and REQUESTS what the push needs of the EV's
-// row (the accumulators and the four newest stack entries: one cache line for the usual depths); `rf_finish`, after the
-// observation stores and the money terms, consumes it.  A step that pushes nothing -- three in four -- never touches the row, and
-// a push that closes no cycle stores ONE word.
-struct RfTop {
-  double b, a;  // log[tail-1], log[tail-2]
-};
+// A real reversal point `p` arrives (rainflow.reversals yielded it): push it and close every cycle the
+// three-point rule allows (rainflow.extract_cycles, the `while len(points) >= 3` loop).
+// The stack of the EV always starts at slot 0 (`tail` = its size; when the three-point rule drops the FIRST point -- the
+// stack is exactly [a, b, p] then -- the survivor below the top is rewritten to slot 0, so no head index exists and the size
+// alone describes it).  Its newest entry lives in the row header only (s2; s1 caches the one below), the entries below it in
+// the stack words behind the header (struct RfHdr in fleet_device.h).
+// The push is split in two so that its memory round trip hides behind the rest of the step: `rf_begin`, right after the
+// state machine, knows the new sample and therefore whether a reversal point is pushed, and REQUESTS the EV's row (header
+// head, stack top, the two entries below the top two: three 16-byte loads of one cache line); `rf_finish`, after the
+// observation stores and the money terms, consumes it.  A step that pushes nothing -- three in four -- never touches the row.
 struct RfReq {
-  double p;      // the reversal point to push
-  RfAcc acc;     // requested when a point is pushed
-  RfTop top;
-  double w0, w1; // log[tail-3], log[tail-4]
+  double p;        // the reversal point to push
+  RfAccHead acc;   // requested when a point is pushed
+  RfTop top;       // stack[tail-2], stack[tail-1]
+  double w0, w1;   // stack[tail-3], [tail-4] (before the push)
   bool push;
-  bool win;      // w0 / w1 were requested (else the pops read the log)
+  bool win;        // w0 / w1 were requested (else the pops read the stack words)
 };
+// `early`: the row's header and the entries below the top two were already requested at the start of the EV's step (K steps
+// per launch: the same row lines serve all K steps of the launch from the cache, and a wavefront that advances on its own is
+// bound by its own dependent round trips, which this removes from every step that pushes).
 __device__ __forceinline__ void rf_request(const FleetDev& d, const EvIx& i, int tail, RfReq& q) {
   const double* row = rf_row_of(d, i);
-  q.acc = *reinterpret_cast<const RfAcc*>(row);
-  // log[tail-1 .. tail-4]; for a shallow stack the lower ones fall into the row's own header (never used: `nwin`)
-  const double* w = rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 4));  // tail >= 1, RF_HDR_WORDS >= 3
+  q.acc = *reinterpret_cast<const RfAccHead*>(row);
+  q.top = *reinterpret_cast<const RfTop*>(row + 2);
+  // stack[tail-4], stack[tail-3]; for a shallow stack they fall into the row's own header (never used: `nwin`)
+  const double* w = rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 4));  // tail >= 1
   q.w1 = w[0];
   q.w0 = w[1];
-  q.top.a = w[2];
-  q.top.b = w[3];
   q.win = true;
 }
 __device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, double old_deg, double soc_deg, int tail, int& sgn, RfReq& q,
@@ -427,135 +427,95 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, doubl
   if (q.push && !early) rf_request(d, i, tail, q);
 }
 // `top`: the stack top after the push (only written when a point was pushed)
-// `acc_out`: the accumulators after the push (only written when the push closed a cycle)
-__device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAcc& acc_out, uint32_t& err) {
+// `acc_out`: the accumulator head after the push (only written when the push closed a cycle)
+__device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAccHead& acc_out,
+                                          uint32_t& err) {
   if (!q.push) return;
   double* row = rf_row_of(d, i);
-  double* lg = row + RF_HDR_WORDS;
+  double* stk = row + RF_HDR_WORDS;
   if (tail >= d.stack_cap) {  // cannot happen (pushes <= samples < stack_cap); refuse instead of overrunning
     err |= FLEET_DEVERR_TABLE_END;
     return;
   }
   const double p = q.p;
-  double a = q.top.a, b = q.top.b;
+  double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
   const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
   if (!closes) {
-    *rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail)) = p;
+    st_plain(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 1)), b);  // the displaced top joins the stack words; tail >= 1
     tail += 1;
-    top.a = b;
-    top.b = p;
+    top.s1 = b;
+    top.s2 = p;
+    st_plain(reinterpret_cast<RfTop*>(row + 2), top);
     return;
   }
   int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;  // entries below the top two that are in registers
-  int size = tail + 1;                                   // points [.., a, b, p]
+  const double w0 = q.w0, w1 = q.w1;
+  tail += 1;
   const int L = q.acc.rf_len;
   int nc = q.acc.nc;
   double mean_sum = q.acc.mean_sum, dcsum = 0.0;
-  float dod = 0.0f;
   bool has_csum = false;
-  while (size >= 3) {
+  while (tail >= 3) {
     const double X = fabs(p - b), Y = fabs(b - a);
     if (X < Y) break;
     if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
-      const double rng = fabs(a - b);
-      dcsum += cycle_stress(rng, 0.5 * (a + b), (size == 3) ? 0.5 : 1.0, d.self->stress_temp);
-      dod = (float)rng > dod ? (float)rng : dod;
+      dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
       has_csum = true;
     }
     mean_sum += 0.5 * (a + b);
     nc += 1;
-    if (size == 3) {  // Y contains the starting point: half cycle, drop the first point -> [b, p]
-      lg[0] = b;
-      a = b;
-      size = 2;
-    } else {  // full cycle, drop its two points -> [.., p]
-      size -= 2;
-      b = (nwin >= 1) ? q.w0 : lg[size - 2];
-      if (size >= 3) a = (nwin >= 2) ? q.w1 : lg[size - 3];
+    if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
+      stk[0] = b;
+      tail = 2;
+    } else {  // full cycle, drop its two points -> stack = [..., p]: the stack words keep what they have, p lives in s2
+      tail -= 2;
+      if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
+      else b = stk[tail - 2];
+      if (tail >= 3) {
+        if (nwin >= 2) a = w1;                     // stack[tail-3]
+        else a = stk[tail - 3];
+      } else {
+        a = 0.0;
+      }
       nwin = 0;
     }
   }
-  // (b is the entry below p now: after a half cycle the stack is [b, p])
-  lg[size - 1] = p;
-  tail = size;
-  top.a = b;
-  top.b = p;
-  RfAcc out;
+  RfAccHead out;
   out.mean_sum = mean_sum;
   out.nc = nc;
   out.rf_len = L;
+  top.s1 = b;  // stack[tail-2]
+  top.s2 = p;  // stack[tail-1]
   acc_out = out;
-  *reinterpret_cast<RfAcc*>(row) = out;
-  if (has_csum) {
-    RfHdr* hd = reinterpret_cast<RfHdr*>(row);
-    hd->csum += dcsum;  // ("DoD too large" :164-167 is raised when the slice is evaluated)
-    if (dod > hd->maxdod) hd->maxdod = dod;
-  }
+  st_plain(reinterpret_cast<RfAccHead*>(row), out);
+  st_plain(reinterpret_cast<RfTop*>(row + 2), top);
+  if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
 }
 
-// Points that were appended without being counted (Hot.bits PENDING; a batch whose count is done by helper wavefronts, see
-// rf_helper) go through the rule now, one after the other, straight from global memory: the slow form, for the few points the
-// helper has not seen yet on a daily row, and for a kernel that takes over such a batch (K steps per launch, ...).
-// In: tail = entries of the log.  Out: tail = the stack size; everything counted.
-__device__ __forceinline__ void rf_count_pending(const FleetDev& d, const EvIx& i, int& tail) {
-  double* row = rf_row_of(d, i);
-  double* lg = row + RF_HDR_WORDS;
-  RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
-  const int L = hd.rf_len;
-  int sz = hd.sz;
-  for (int j = hd.upto; j < tail; ++j) {
-    const double p = lg[j];
-    while (sz >= 2) {  // points [.., a, b, p]
-      const double b = lg[sz - 1], a = lg[sz - 2];
-      if (fabs(p - b) < fabs(b - a)) break;
-      if (hd.nc >= L - 1) {
-        const double rng = fabs(a - b);
-        hd.csum += cycle_stress(rng, 0.5 * (a + b), (sz == 2) ? 0.5 : 1.0, d.stress_temp);
-        hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;
-      }
-      hd.mean_sum += 0.5 * (a + b);
-      hd.nc += 1;
-      if (sz == 2) {  // half cycle: drop the first point
-        lg[0] = b;
-        sz = 1;
-        break;
-      }
-      sz -= 2;
-    }
-    lg[sz] = p;  // (sz <= j: in place)
-    sz += 1;
-  }
-  hd.sz = sz;
-  hd.upto = sz;
-  *reinterpret_cast<RfHdr*>(row) = hd;
-  tail = sz;
-}
-
-// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212), every logged
-// reversal point counted: `v` = the sample just logged (rainflow.reversals always yields the last sample), `n` = number of logged
-// samples, the counted stack is log[0 .. sz).
-//   1. the forced last point and the residual half cycles are evaluated on a virtual copy of the stack (vt, vh, registers);
-//      the counted state is not modified by them;
-//   2. the SEI model, when the cycle list has grown beyond rainflow_length (:144).
-__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int sz, uint32_t& err, double dt_hours,
-                                             int* new_len = nullptr) {
+// RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
+// `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
+// residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
+// is modified except rainflow_length / fd_cyc / fd_cal / l / csum when the reference would update them.
+// `top` / `have_top`: the stack top when this step's push has just written it (registers are newer than the row).
+__device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix, double v, int n, int tail, const RfTop& top, bool have_top,
+                                             uint32_t& err, double dt_hours, int* new_len = nullptr) {
   const size_t i = ix.flat();
   double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  const double* lg = row + RF_HDR_WORDS;
+  const double* stk = row + RF_HDR_WORDS;
   // everything this needs from memory is requested up front (one round trip)
-  RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
+  const RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
   SeiRec sr = d.sei[i];
-  double b = lg[sz - 1];
-  double a = lg[sz >= 2 ? sz - 2 : 0];
-  const int L = hd.rf_len, nc = hd.nc;
+  const int L = hd.rf_len;
+  const int nc = hd.nc;
+  const double mean_sum0 = hd.mean_sum, csum0 = hd.csum, fd_cyc0 = sr.fd_cyc, sei_l0 = sr.sei_l, sei_soh0 = sr.sei_soh;
   const double st = d.stress_temp;
 #ifdef FLEET_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   FLEET_STAMP(11);  // records arrived
-  double max_dod = (double)hd.maxdod;  // over the closed cycles of the slice (rf_finish; rounded to float32: the test is `> 5`)
+
   int nv = 0;
-  double vmean = 0.0, vsum = 0.0, pend = 0.0;
+  double vmean = 0.0, vsum = 0.0, pend = 0.0, max_dod = 0.0;
   bool has_pend = false;
   auto emit = [&](double x1, double x2, double count) {
     if (has_pend) vsum += pend;  // the previous cycle is not the last one
@@ -570,8 +530,9 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
     nv += 1;
   };
   if (n >= 3) {  // with two samples rainflow.reversals yields only the first point: no cycle at all
-    int vt = sz, vh = 0;
+    int vt = tail, vh = 0;
     int size = vt - vh + 1;
+    double a = have_top ? top.s1 : hd.s1, b = have_top ? top.s2 : hd.s2;
     while (size >= 3) {
       const double X = fabs(v - b), Y = fabs(b - a);
       if (X < Y) break;
@@ -582,208 +543,52 @@ __device__ __forceinline__ double sei_evaluate(const FleetDev& d, const EvIx& ix
       } else {
         vt -= 2;
         size -= 2;
-        b = lg[vt - 1];
-        a = (size >= 3) ? lg[vt - 2] : 0.0;
+        b = stk[vt - 1];
+        a = (size >= 3) ? stk[vt - 2] : 0.0;
       }
     }
-    // remaining ranges are half cycles: log[vh .. vt) followed by the forced point
-    double prev = lg[vh];
+    // remaining ranges are half cycles: stack[vh..vt) followed by the forced point
+    double prev = (vt - vh >= 2) ? stk[vh] : b;
     for (int j = vh + 1; j < vt; ++j) {
-      const double cur = lg[j];
+      const double cur = (j == vt - 1) ? b : stk[j];
       emit(prev, cur, 0.5);
       prev = cur;
     }
-    emit(prev, v, 0.5);
+    emit(b, v, 0.5);
   }
 
   FLEET_STAMP(12);  // stack walked, cycle stresses evaluated
   double degradation = 0.0;
-  double sei_l = sr.sei_l;
+  double sei_l = sei_l0;
   const int len = nc + nv;
   if (len > 0 && len > L) {
     if (max_dod > 5.0) err |= FLEET_DEVERR_DOD_RANGE;
     const double battery_age = (double)(n - 1) * dt_hours * 3600.0;  // max(End) is always the last sample's index
-    const double mean_soc_cal = (hd.mean_sum + vmean) / (double)len;
-    const double fd_cyc = sr.fd_cyc + (hd.csum + vsum);
+    const double mean_soc_cal = (mean_sum0 + vmean) / (double)len;
+    const double fd_cyc = fd_cyc0 + (csum0 + vsum);
     const double fd_cal = (4.14E-10 * battery_age) * exp(1.04 * (mean_soc_cal - 0.5)) * st;
     const double fd = fd_cyc + fd_cal;
     const double alpha = 5.75E-2, beta = 121.0;
     sei_l = 1.0 - alpha * exp(-beta * fd) - (1.0 - alpha) * exp(-fd);
     if (sei_l < 0.0) err |= FLEET_DEVERR_NEG_LIFE;
-    degradation = sei_l - sr.sei_l;
+    degradation = sei_l - sei_l0;
     sr.fd_cyc = fd_cyc;
     sr.fd_cal = fd_cal;
     sr.sei_l = sei_l;
-    // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
-    RfAcc out;
-    out.mean_sum = hd.mean_sum;
+    RfAccHead out;  // rainflow_length moves on; every closed cycle so far now lies below the new rainflow_length-1
+    out.mean_sum = mean_sum0;
     out.nc = nc;
     out.rf_len = len;
-    *reinterpret_cast<RfAcc*>(row) = out;
+    *reinterpret_cast<RfAccHead*>(row) = out;
     reinterpret_cast<RfHdr*>(row)->csum = 0.0;
-    reinterpret_cast<RfHdr*>(row)->maxdod = 0.0f;
     if (new_len) *new_len = len;
   }
   FLEET_STAMP(13);  // SEI model evaluated
-  const double s = sr.sei_soh - degradation;
+  const double s = sei_soh0 - degradation;
   sr.sei_soh = s;
   d.sei[i] = sr;
   if (fabs(s - (1.0 - sei_l)) > 0.0001) err |= FLEET_DEVERR_SOH_MISMATCH;
   return degradation;
-}
-
-// ---- the helper wavefront -------------------------------------------------------------------------------------------------
-// One step per launch with one env per wavefront (the drop-in path at the BASELINE shapes): a launch lasts as long as its
-// slowest wavefront and moves what all of them touch.  Counting a reversal point in the step that finds it (rf_begin / rf_finish)
-// costs every wavefront of every launch a cold line of the EV's row per pushing lane and the closure loop -- 1.8 of 8.5 us at
-// 4096 x 50 (the same kernel with the count switched off: 6.7 us, profiles/r04_experiments/lazy_floor.log).  Counting in batches
-// inside the env's own wavefront makes that wavefront the one the launch waits for (measured: every 8th row, and only on the
-// daily row; same directory).  So the env's wavefront only APPENDS reversal points (one store, Hot.bits PENDING), and the points
-// of a day are counted, in the two launches before the env's daily row, by a FIFTH wavefront of the env's workgroup that has
-// nothing else to do: it runs beside the four env wavefronts in the SIMDs' free issue slots and ends long before they do.
-//   * the env's wavefront, at the end of a step from which the daily row is three (two) launches away, writes the sizes of its
-//     EVs' logs to `rf_snap` and (three away) sets `rf_need[e] = 2`; it does so only if no episode end lies in between;
-//   * the helper of the workgroup finds rf_need[e] > 0, counts log[upto .. snap) of the env's EVs -- staged in the LDS: the
-//     newest stack entries and the pending points, copied by the memory system (global_load_lds), the count itself a loop without
-//     branches on its common paths that 64 lanes with 64 different point sequences walk together --, writes stack and header
-//     back and decrements rf_need[e].  It touches only log entries below `snap` and the header; the env's wavefront, in the same
-//     launch, only appends at or above `snap` and does not read the header before its daily row: no race;
-//   * the env's wavefront on its daily row counts what is left (the points of the last two steps and of the daily step itself,
-//     or everything if no helper ran: an episode that starts right before a daily row) with rf_count_pending and evaluates.
-typedef __attribute__((address_space(3))) char fleet_lds_char;
-typedef __attribute__((address_space(3))) double fleet_lds_double;
-typedef __attribute__((address_space(3))) fleet_v4f fleet_lds_v4f;
-constexpr int kHelperUnits = 32;                       // 16-byte units per lane staged: 64 log entries
-constexpr int kHelperLdsBytes = kHelperUnits * 64 * 16;  // unit u of lane r at byte (u * 64 + r) * 16: what global_load_lds produces
-constexpr int kHelperStackUnits = 7;                   // ... of which the newest (up to) 14 stack entries
-constexpr int kHelperTurns = 48;                       // turns of the counting loop per env and launch
-
-// All lanes of the helper wavefront; lane c handles EV c of env e.
-__device__ __forceinline__ void rf_helper_env(const FleetDev& d, int e, uint32_t snap, fleet_lds_char* lds) {
-  const int lane = (int)(threadIdx.x & 63u);
-  const int N = d.N;
-  const bool has = lane < N;
-  const EvIx ix = {(size_t)e * N, (unsigned)(has ? lane : N - 1)};
-  const size_t i = ix.flat();
-  double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-  double* lg = row + RF_HDR_WORDS;
-  RfHdr hd = *reinterpret_cast<const RfHdr*>(row);
-  const int S = HOT_TAIL(snap);
-  const bool work = has && HOT_PEND(snap) && hd.upto < S;
-  // what is staged: log[lo .. sz) (the newest stack entries) as LDS entries 0 .., then log[ub .. Sb) from LDS entry pb on
-  int sz = work ? hd.sz : 0;
-  int lo = sz - 2 * kHelperStackUnits;
-  lo = lo < 0 ? 0 : (lo + 1) & ~1;
-  const int nA = (sz - lo + 1) >> 1;                           // units of the stack part
-  const int ub = work ? (hd.upto & ~1) : 0;                    // first staged entry of the pending part (unit-aligned)
-  int Sb = ub + 2 * (kHelperUnits - nA);
-  Sb = work ? (Sb < S ? Sb : S) : 0;
-  const int nB = (Sb - ub + 1) >> 1;
-  const unsigned m0_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)lds);
-  const char* srcA = reinterpret_cast<const char*>(lg + lo);
-  const char* srcB = reinterpret_cast<const char*>(lg + ub) - (size_t)nA * 16;  // so that unit u >= nA reads pending unit u - nA
-#pragma unroll 4
-  for (int u = 0; u < kHelperUnits; ++u) {
-    if (!__any(u < nA + nB)) break;
-    if (u < nA + nB) {
-      const char* src = (u < nA ? srcA : srcB) + u * 16;
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0_base + u * 1024), "v"(src) : "memory", "m0");
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  fleet_lds_char* const col = lds + lane * 16;
-  auto at = [&](int k) -> fleet_lds_char* { return col + ((k >> 1) << 10) + ((k & 1) << 3); };
-  auto ld = [&](fleet_lds_char* q) -> double { return *reinterpret_cast<const fleet_lds_double*>(q < col ? col : q); };
-  // LDS entry indices: the stack is entries [0, szl), the next point to count is entry j
-  int szl = sz - lo;
-  int left = work ? Sb - hd.upto : 0;                 // staged points still to be counted
-  int j = 2 * nA + (hd.upto & 1);
-  const int L = hd.rf_len;
-  int nc = hd.nc;
-  double mean_sum = hd.mean_sum;
-  fleet_lds_char* As = at(szl);
-  int step = (szl & 1) ? 1016 : 8;
-  fleet_lds_char* Jc = at(j);
-  int jstep = (j & 1) ? 1016 : 8;
-  double b = ld(As - 1024 + step), a = ld(As - 1024), c = ld(As - 2048 + step), dd = ld(As - 2048);
-  double p = ld(Jc), p_nx = ld(Jc + jstep);
-  int szmin = szl;
-  int turns = kHelperTurns;
-  bool changed = false;
-  // (a lane whose staged stack runs low while deeper entries exist in global memory stops: the env's wavefront finishes the count)
-  while (left > 0 && turns-- > 0 && !(lo > 0 && szl < 4)) {
-    const bool closes = (szl >= 2) && !(fabs(p - b) < fabs(b - a));
-    if (__builtin_expect(closes && nc >= L - 1, 0)) {  // only the closed cycles beyond the last evaluation's count carry stress
-      const double rng = fabs(a - b);
-      hd.csum += cycle_stress(rng, 0.5 * (a + b), (lo + szl == 2) ? 0.5 : 1.0, d.stress_temp);
-      hd.maxdod = (float)rng > hd.maxdod ? (float)rng : hd.maxdod;
-      changed = true;
-    }
-    mean_sum = fma(a + b, closes ? 0.5 : 0.0, mean_sum);  // += 0.5 * (a + b): the product is exact, so one rounding either way
-    nc += closes ? 1 : 0;
-    // closes, 2 points : Y contains the starting point: half cycle, drop the first point -> the stack is [b]; p is pushed next turn
-    // closes, more     : full cycle, drop its two points -> [.., c, d]; p again next turn
-    // else             : push, log[sz] = p
-    const bool half = closes && (lo + szl == 2);
-    if (!closes || half) *reinterpret_cast<fleet_lds_double*>(half ? col : As) = half ? b : p;
-    As = half ? col + 8 : (closes ? As - 1024 : As + step);
-    step = half ? 1016 : (closes ? step : 1024 - step);
-    szl = half ? 1 : szl + (closes ? -2 : 1);
-    szmin = half ? 0 : (szl < szmin ? szl : szmin);
-    a = closes ? dd : b;
-    b = half ? b : (closes ? c : p);
-    c = ld(As - 2048 + step);
-    dd = ld(As - 2048);
-    Jc = closes ? Jc : Jc + jstep;
-    jstep = closes ? jstep : 1024 - jstep;
-    left -= closes ? 0 : 1;
-    p = closes ? p : p_nx;
-    p_nx = ld(Jc + jstep);
-  }
-  if (work) {
-    // the stack entries that were rewritten go back to log[lo + szmin ..); the points still pending stay where they are
-    // (whole 16-byte units, and the last entry alone when the stack size is odd: the word behind it may be a pending point)
-    for (int u = (szmin < szl ? szmin : szl) >> 1; u < (szl >> 1); ++u)
-      *reinterpret_cast<fleet_v4f*>(lg + lo + 2 * u) = *reinterpret_cast<const fleet_lds_v4f*>(col + u * 1024);
-    if ((szl & 1) && szmin < szl) lg[lo + szl - 1] = *reinterpret_cast<const fleet_lds_double*>(at(szl - 1));
-    RfAcc acc;
-    acc.mean_sum = mean_sum;
-    acc.nc = nc;
-    acc.rf_len = L;
-    *reinterpret_cast<RfAcc*>(row) = acc;
-    if (changed) {
-      reinterpret_cast<RfHdr*>(row)->csum = hd.csum;
-      reinterpret_cast<RfHdr*>(row)->maxdod = hd.maxdod;
-    }
-    RfMark mk;
-    mk.sz = lo + szl;
-    mk.upto = Sb - left;
-    *reinterpret_cast<RfMark*>(row + 4) = mk;
-  }
-}
-
-// The fifth wavefront of a workgroup of the one-step-per-launch kernel: counts for the workgroup's four envs.
-// rf_need / rf_snap are read BEFORE the workgroup's barrier and written by the env wavefronts (at the end of their step) BEHIND
-// it: what the helper sees was written by an earlier launch, whatever the order in which the five wavefronts run.
-__device__ __forceinline__ void rf_helper(const FleetDev& d, int e0, fleet_lds_char* lds) {
-  const int lane = (int)(threadIdx.x & 63u);
-  auto need_of = [&](int w) -> int { return (e0 + w < d.E) ? __builtin_amdgcn_readfirstlane(d.rf_need[e0 + w]) : 0; };
-  auto snap_of = [&](int w, int need) -> uint32_t {
-    return (need > 0 && lane < d.N) ? (uint32_t)d.rf_snap[(size_t)(e0 + w) * d.N + lane] : 0u;
-  };
-  const int n0 = need_of(0), n1 = need_of(1), n2 = need_of(2), n3 = need_of(3);
-  const uint32_t s0 = snap_of(0, n0), s1 = snap_of(1, n1), s2 = snap_of(2, n2), s3 = snap_of(3, n3);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  auto serve = [&](int w, int need, uint32_t snap) {
-    if (need <= 0) return;
-    rf_helper_env(d, e0 + w, snap, lds);
-    if (lane == 0) d.rf_need[e0 + w] = need - 1;
-  };
-  serve(0, n0, s0);
-  serve(1, n1, s1);
-  serve(2, n2, s2);
-  serve(3, n3, s3);
 }
 
 // EmpiricalDegradation.calculate_degradation for one EV (empirical_degradation.py:29-99; quirks Q1, Q5):
@@ -804,7 +609,7 @@ __device__ __forceinline__ double linear_degradation(const FleetDev& d, double o
 // The hot record of an EV whose soc / soc_deg / hours_left are given (struct Hot in fleet_device.h): the shared float64
 // field, the FROZEN / INPLANE flags, and the soc_deg plane entry in the one case that needs it.  `plane_has` = the
 // plane already holds this soc_deg (the EV was INPLANE before and soc_deg has not changed since).
-__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, bool pend, int sgn,
+__device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, double soc, double soc_deg, float hl, int tail, int sgn,
                                           uint32_t there, bool t090, bool plane_has) {
   Hot h;
   h.hl = hl;
@@ -819,7 +624,7 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
       if (!plane_has) d.soc_deg[i.flat()] = soc_deg;
     }
   }
-  h.bits = HOT_PACK(tail, pend, sgn, frozen, inplane, there, t090);
+  h.bits = HOT_PACK(tail, sgn, frozen, inplane, there, t090);
   return h;
 }
 
@@ -844,9 +649,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     const EvIx ix = {(size_t)e * N, (unsigned)c};
     const size_t i = ix.flat();
     const SegRec s0 = d.seg[(size_t)start * N + c];
-    // the record the first step of the episode advances to (as one 16-byte word: a struct temporary that is only copied through
-    // stays a private-memory object, which costs the kernels that use the LDS scratch memory)
-    const fleet_v4f s1 = *reinterpret_cast<const fleet_v4f*>(&d.seg[(size_t)next * N + c]);
+    const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
     const RowRec tb = seg_row(s0, start, d.dt);
     const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
     const double soh = 1.0 * cd->init_soh;
@@ -858,20 +661,18 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
       soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
     const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, false, 0, tb.there, t090, false);  // rainflow: the log is [first sample]
-    *reinterpret_cast<fleet_v4f*>(&d.run[i]) = s1;
+    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
+    d.run[i] = s1;
     d.soh[i] = soh;
     if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      double* row = d.rf_rows + i * (size_t)d.rf_row_stride;
-      RfHdr hd = *reinterpret_cast<const RfHdr*>(row);  // rainflow_length survives
+      RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
+      RfHdr hd = *hp;  // rainflow_length survives
       hd.mean_sum = 0.0;
-      hd.nc = 0;
       hd.csum = 0.0;
-      hd.maxdod = 0.0f;
-      hd.sz = 1;
-      hd.upto = 1;
-      *reinterpret_cast<RfHdr*>(row) = hd;
-      row[RF_HDR_WORDS] = soc_deg;  // the log is [soc_deg]: the first sample is the first reversal point
+      hd.nc = 0;
+      hd.s1 = 0.0;
+      hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
+      *hp = hd;
     }
     if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
     if (log_on) {
@@ -920,44 +721,19 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   int lp = d.log_pos ? d.log_pos[e] : 0;
   reset_env<G, true>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
-  if (d.rf_need && g == G - 1) d.rf_need[e] = 0;  // the rainflow helper has nothing to count for a fresh episode
 }
 
 // The tail of an EV's step: the rainflow push (second half), the linear model's daily update, the data-log row, and the
 // stores of the state records that changed.
-template <int DEG, bool WIDE, bool LAZY>
+template <int DEG, bool WIDE>
 __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int c, int N, bool env_ok, bool deg_row, double dt_step, const RfReq& rq,
-                                          int tail, bool pend, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
+                                          int tail, int sgn, double soc, double soc_deg, double old_deg, float hl, uint32_t there1,
                                           bool t090, bool inplane, bool crosses, const SegRec& nr, double soh0, double a, double en, bool logs,
                                           size_t lrow, const Hot& h_in, uint32_t& err, double& sei_sample, double& sei_soh, int& sei_tail,
-                                          uint32_t& bits_out, RfAcc& acc_c, RfTop& top_c, bool carry) {
+                                          RfTop& sei_top, bool& sei_have_top, RfAccHead& acc_c, RfTop& top_c, bool carry) {
   double soh = soh0;
   RfTop top = top_c;
-  if (DEG == FLEET_DEG_RAINFLOW && env_ok && !LAZY) rf_finish(d, i, rq, tail, top, acc_c, err);
-  if (DEG == FLEET_DEG_RAINFLOW && env_ok && LAZY) {
-    // a helper wavefront counts for this batch (rf_helper): the reversal point is appended, nothing is read.  The first
-    // point behind a count also marks where the stack ends (RfHdr.sz / .upto, one 8-byte store into the same line).
-    if (rq.push) {
-      if (tail >= d.self->stack_cap) {
-        err |= FLEET_DEVERR_TABLE_END;
-      } else {
-        double* row = rf_row_of(d, i);
-        row[RF_HDR_WORDS + tail] = rq.p;
-        if (!pend) {
-          RfMark mk;
-          mk.sz = tail;
-          mk.upto = tail;
-          *reinterpret_cast<RfMark*>(row + 4) = mk;
-        }
-        pend = true;
-        tail += 1;
-      }
-    }
-    if (deg_row && pend) {  // the daily evaluation needs every point counted: what the helper has left (this step's and the
-      rf_count_pending(*d.self, i, tail);  // last two steps' points), or all of them if none ran
-      pend = false;
-    }
-  }
+  if (DEG == FLEET_DEG_RAINFLOW && env_ok) rf_finish(d, i, rq, tail, top, acc_c, err);
   const bool pushed = rq.push;
   if (carry && pushed) top_c = top;
   if (DEG == FLEET_DEG_LINEAR && deg_row) soh = soh - linear_degradation(d, old_deg, soc_deg, dt_step);
@@ -965,6 +741,8 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
     sei_sample = soc_deg;
     sei_soh = soh0;
     sei_tail = tail;
+    sei_top = top;
+    sei_have_top = pushed || carry;
   }
   if (logs) {  // action, energy, degradation, SoH (rainflow: the daily pass below overwrites the last two on its row)
     double* lev = d.log_ev + lrow * 4 * N + c;
@@ -974,12 +752,11 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
     lev[3 * N] = soh;
   }
   FLEET_STAMP(5);
-  if (LAZY) bits_out = HOT_PACK(tail, pend, 0, false, false, 0, false);  // size of the log and PENDING, for the helper's snapshot
   if (env_ok) {
     // soc_deg == soc whenever the EV has hours left; otherwise it keeps its previous value, which shares the record's float64
     // field with an empty slot's soc == 0.  An EV that is away and stays away leaves its record as it was: no store (what a
     // launch leaves dirty in the L2 is written back before it ends; a third of a caretaker fleet's EV-steps).
-    const Hot h_out = hot_encode(d, i, soc, soc_deg, hl, tail, LAZY && pend, sgn, there1, t090, inplane);
+    const Hot h_out = hot_encode(d, i, soc, soc_deg, hl, tail, sgn, there1, t090, inplane);
     const bool same = (__double_as_longlong(h_out.x) == __double_as_longlong(h_in.x)) &&
                       (__float_as_uint(h_out.hl) == __float_as_uint(h_in.hl)) && (h_out.bits == h_in.bits);
     if (!same) st_rec16(ev_at(d.hot, i), h_out);
@@ -996,8 +773,8 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
 // For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
-template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false, bool LAZY = false>
-__global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
+template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
+__global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
     // its lanes' state records and action, E and N for their addresses -- is passed here once more, ahead of the argument
@@ -1008,12 +785,6 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
-  static_assert(!LAZY || (G == 64 && DEG == FLEET_DEG_RAINFLOW && !MULTI && !WIDE && !LOG), "the helper wavefront serves one env per wavefront");
-  __shared__ __attribute__((aligned(16))) char rf_lds[LAZY ? kHelperLdsBytes : 16];
-  if (LAZY && threadIdx.x >= kBlock) {  // the workgroup's fifth wavefront (rf_helper)
-    rf_helper(d, (int)blockIdx.x * (kBlock / G), (fleet_lds_char*)rf_lds);
-    return;
-  }
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
   const int N = p_N, E_ = p_E;
@@ -1050,7 +821,6 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
   }
 
   EnvHead r = p_env[e].h;
-  if (LAZY) __builtin_amdgcn_s_barrier();  // the helper wavefront has read rf_need / rf_snap (rf_helper); costs nothing: the loads above are in flight
   if (G == 64) {
     r.t = __builtin_amdgcn_readfirstlane(r.t);
     r.t_end = __builtin_amdgcn_readfirstlane(r.t_end);
@@ -1100,21 +870,13 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
   // -14 % K-step rate -- the kernel is at the 128-register limit of four resident wavefronts per SIMD, the six extra live
   // registers spill, and those loads overlap with other wavefronts' arithmetic anyway;
   // profiles/r03_experiments/ab_stcarry.log.)
-  RfAcc acc_c = {0.0, 0, 0};
+  RfAccHead acc_c = {0.0, 0, 0};
   RfTop top_c = {0.0, 0.0};
-  auto carry_load = [&]() {  // (the log's size lives in the hot record: a dependent load, once per launch)
+  auto carry_load = [&]() {
     const EvIx i0 = {(size_t)e * N, (unsigned)(g < N ? g : N - 1)};
     const double* row = rf_row_of(d, i0);
-    Hot* hp = ev_at(d.hot, i0);
-    uint32_t bits = hp->bits;
-    int T = HOT_TAIL(bits);
-    if (HOT_PEND(bits) && env_ok && g < N) {  // a batch the helper wavefronts were counting for (rf_helper): catch up first
-      rf_count_pending(*d.self, i0, T);
-      hp->bits = (bits & ~0x3FFFFFFu) | (uint32_t)T;
-    }
-    acc_c = *reinterpret_cast<const RfAcc*>(row);
-    top_c.b = row[RF_HDR_WORDS + T - 1];
-    top_c.a = row[RF_HDR_WORDS + (T >= 2 ? T - 2 : 0)];
+    acc_c = *reinterpret_cast<const RfAccHead*>(row);
+    top_c = *reinterpret_cast<const RfTop*>(row + 2);
   };
   if (kRfCarry) carry_load();
   double last_rew = 0.0;
@@ -1197,7 +959,8 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
     // the few wavefronts on the 14:45 row, which otherwise finish last and set the launch's duration)
     double sei_sample = 0.0, sei_soh = 0.0;
     int sei_tail = 0;
-    uint32_t snap_bits = 0;
+    RfTop sei_top = {0.0, 0.0};
+    bool sei_have_top = false;
     bool ev_lane = false;  // real_time: something the reference counts into episode.events happened to this lane's EVs
     // Several EVs per lane, one step per launch (N > 64): the lane's NEXT EV's records are requested before the current EV is
     // worked on (software pipelining of the lane loop) -- otherwise every turn of the loop starts with a memory round trip
@@ -1231,13 +994,6 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
       const bool inplane = HOT_INPLANE(hb.bits);
       double old_deg = hb.x;
       if (inplane) old_deg = d.soc_deg[i.flat()];
-      // (a batch the helper wavefronts were counting for, rf_helper: catch up first -- only the first launch of another kind)
-      int tail = HOT_TAIL(hb.bits);
-      bool pend = (DEG == FLEET_DEG_RAINFLOW) && HOT_PEND(hb.bits);
-      if (!LAZY && pend && !kRfCarry && env_ok) {
-        rf_count_pending(*d.self, i, tail);
-        pend = false;
-      }
       RfReq rq;
       rq.push = false;
       constexpr bool kRfEarly = MULTI && DEG == FLEET_DEG_RAINFLOW;
@@ -1246,7 +1002,7 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
         rq.acc = acc_c;
         rq.top = top_c;
       } else if (kRfEarly && env_ok) {
-        rf_request(d, i, tail, rq);
+        rf_request(d, i, HOT_TAIL(hb.bits), rq);
       }
       double a;
       if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
@@ -1341,11 +1097,11 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
       const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
       // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
       // here and consumed after the observation stores and the money terms
-      int sgn = HOT_SGN(hb.bits);
+      int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
       // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
       // stores would cost the multi-step kernel a resident wavefront per SIMD)
       constexpr bool kSplitRf = !MULTI;
-      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, LAZY);  // (LAZY: no request)
+      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
@@ -1364,8 +1120,9 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
       if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
-      ev_finish<DEG, WIDE, LAZY>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, pend, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
-                           crosses, nr, soh0, a, en, logs, lrow, hb, err, sei_sample, sei_soh, sei_tail, snap_bits, acc_c, top_c, kRfCarry);
+      ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
+                           crosses, nr, soh0, a, en, logs, lrow, hb, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c,
+                           top_c, kRfCarry);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
@@ -1426,12 +1183,14 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
         const size_t i = ix.flat();
         double deg, soh_new;
         if (!WIDE) {
-          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, err, dt_step, kRfCarry ? &acc_c.rf_len : nullptr);
+          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
+                             kRfCarry ? &acc_c.rf_len : nullptr);
           soh_new = sei_soh - deg;
         } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
           const Hot hb = d.hot[i];
           const double sample = HOT_INPLANE(hb.bits) ? d.soc_deg[i] : hb.x;
-          deg = sei_evaluate(*d.self, ix, sample, r.nsamp, HOT_TAIL(hb.bits), err, dt_step);
+          const RfTop none = {0.0, 0.0};
+          deg = sei_evaluate(*d.self, ix, sample, r.nsamp, HOT_TAIL(hb.bits), none, false, err, dt_step);
           soh_new = d.soh[i] - deg;
         }
         d.soh[i] = soh_new;
@@ -1469,18 +1228,6 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
         penalty_record = 0.0;
       }
     }
-    if (LAZY && env_ok && !head_reset) {
-      // Hand the day's count to the workgroup's helper wavefront (rf_helper): when the daily row is three launches away (and no
-      // episode end lies before it) the helper gets two launches; the sizes of the EVs' logs as of now are its work list, and
-      // are refreshed once more a launch later.  (Behind the workgroup's barrier: the helper of THIS launch has read both.)
-      const int tn = r.t, Tl = d.T - 1;
-      const bool q3 = (tn + 3 <= Tl) && (d.tab_flags[tn + 3 <= Tl ? tn + 3 : Tl] & FLEET_TFLAG_DEG) && (r.t_end > tn + 2);
-      const bool q2 = (tn + 2 <= Tl) && (d.tab_flags[tn + 2 <= Tl ? tn + 2 : Tl] & FLEET_TFLAG_DEG);
-      if (q3 || q2) {
-        if (g < N) d.rf_snap[(size_t)e * N + g] = (int32_t)snap_bits;
-        if (leader && q3) d.rf_need[e] = 2;
-      }
-    }
     if (rt) {
       // EventManager.check_event (event_manager.py:16-31): the advanced row's clock minute == 15 is an event of its own;
       // the end of the episode is one (:629); running off the table ends the loop (the reference would raise there)
@@ -1507,7 +1254,6 @@ __global__ __launch_bounds__(LAZY ? kBlock + 64 : kBlock, MULTI ? (WIDE ? kMulti
     er->ep_len = ep_len;
     er->penalty_record = penalty_record;
     if (log_on) d.log_pos[e] = lp;
-    if (!LAZY && DEG == FLEET_DEG_RAINFLOW && d.rf_need) d.rf_need[e] = 0;  // (a helper window of the env, if any, is void now)
     if (MULTI) {
       reward[e] = rt ? last_rew : reward_sum;
       if (done && (rt || steps == 1)) done[e] = (rt ? last_done : (n_done != 0)) ? 1 : 0;  // one agent step: its done flag
@@ -1645,14 +1391,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
   } else {
-    constexpr bool kLazy = (G == 64 && DEG == FLEET_DEG_RAINFLOW);  // one env per wavefront: a fifth wavefront per workgroup counts
-    if (single && kLazy && d.rf_need && f64 == FLEET_ACT_F64)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, true, kLazy>), grid, dim3(kBlock + 64), 0, s, FLEET_PRE_ARGS d, actions,
-                         f64, 1, obs, reward, done, terminal_obs, done_count);
-    else if (single && kLazy && d.rf_need)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, false, kLazy>), grid, dim3(kBlock + 64), 0, s, FLEET_PRE_ARGS d, actions,
-                         f64, 1, obs, reward, done, terminal_obs, done_count);
-    else if (single && f64 == FLEET_ACT_F64)
+    if (single && f64 == FLEET_ACT_F64)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
                          reward, done, terminal_obs, done_count);
     else if (single)

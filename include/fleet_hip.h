@@ -76,7 +76,7 @@ typedef struct FleetParams {
   int32_t num_cars;         /* N  (db["ID"].max()+1, fleet_environment.py:260) */
   int32_t table_rows;       /* T */
   int32_t episode_steps;    /* episode_length[h] * steps_per_hour; finish = start + episode_steps (:355).  Rainflow mode:
-                               < 2^25 - 3, and num_cars * (episode_steps + 24) * 8 bytes < 4 GiB */
+                               < 2^26 - 3, and num_cars * (episode_steps + 24) * 8 bytes < 4 GiB */
   int32_t price_lookahead;  /* L  (time_config.py:14) */
   int32_t bl_pv_lookahead;  /* B  (time_config.py:15) */
   int32_t steps_per_hour;   /* 60 / minutes */

@@ -169,16 +169,16 @@ def _create_status(p, tables, time_feat):
 
 def test_create_accepts_long_episodes_in_rainflow_mode():
     """The reference accepts any `episode_length` (time_config.py:1-24, fleet_environment.py:355).  The rainflow stack size
-    travels in a 25-bit field of the hot record, so only episodes beyond 33 million steps are rejected (round 2 stopped at
+    travels in a 26-bit field of the hot record, so only episodes beyond 67 million steps are rejected (round 2 stopped at
     8188 steps = 85 days); the config layer has no limit of its own any more."""
     g = load_trace("ct5_both_rainflow")
     p = params_for(g)
     p.episode_steps = 24 * 4 * 365  # a whole year at 15 min: the status then only depends on the device
     rc, msg = _create_status(p, g.tables, g.time_feat)
     assert rc != _capi.ERR_INVALID, msg
-    p.episode_steps = (1 << 25) - 2
+    p.episode_steps = (1 << 26) - 2
     rc, msg = _create_status(p, g.tables, g.time_feat)
-    assert rc == _capi.ERR_INVALID and "33 million" in msg
+    assert rc == _capi.ERR_INVALID and "67 million" in msg
     p.deg_mode = _capi.DEG_LINEAR  # no stack: any length goes
     rc, msg = _create_status(p, g.tables, g.time_feat)
     assert rc != _capi.ERR_INVALID
@@ -194,10 +194,10 @@ def test_create_rejects_rainflow_rows_beyond_a_32_bit_offset():
     from fleetrl_amd.synth import synth_tables
 
     cfg = dict(_cfg(), use_case="ut", episode_length=24)
-    tb = synth_tables("ut", 20, seed=3)
+    tb = synth_tables("ut", 16, seed=3)
     p = make_params(resolve_config(cfg), tb, 2, seed=0)
     tf = time_features(tb)
-    p.episode_steps = 30_000_000  # 20 EVs x 30 M log words x 8 B = 4.8 GB per env
+    p.episode_steps = 40_000_000  # 16 EVs x 40 M stack words x 8 B = 5.1 GB per env
     rc, msg = _create_status(p, tb, tf)
     assert rc == _capi.ERR_INVALID and "4 GiB" in msg
     p.episode_steps = 24 * 4 * 365
