@@ -228,19 +228,24 @@ class FleetBatch:
     def step(self, actions, copy: bool = True):
         """-> (obs f32[E,obs_dim], reward f64[E], done u8[E], terminal_obs f32[E,obs_dim]); `terminal_obs` is a buffer
         reused between calls whose rows are valid only where `done` is set.
-        The observation transfer lands in one of OBS_RING pinned buffers used in turn.  `copy=True` (default) returns a private
-        copy of it, like the reference's env returns a fresh array every step.  `copy=False` returns the pinned buffer itself
-        (no 4 * E * obs_dim byte copy on the host): it is overwritten OBS_RING calls later -- enough for an SB3 loop, which
+        `copy=True` (default) returns a fresh array, like the reference's env does every step (the transfer is pipelined with the
+        host copy inside the library).  `copy=False` lands the transfer in one of OBS_RING pinned buffers used in turn and returns
+        that buffer itself (no 4 * E * obs_dim byte copy on the host): it is overwritten OBS_RING calls later -- enough for an SB3 loop, which
         holds the previous observation while it steps and copies what it keeps; not for code that collects observations in a
         list.  Either way the memory stays valid for as long as the returned array is referenced -- with `copy=False` that is
         page-locked memory (E * obs_dim * 4 bytes per retained array), which stays pinned until the array is dropped."""
         a, dt = self._act(actions, (self.E, self.N))
         if _PinnedBuffer._dead:
             _PinnedBuffer.drain()
-        if len(self._obs_ring) < self.OBS_RING:
-            self._obs_ring.append(self.pinned_array((self.E, self.obs_dim)))
-        obs = self._obs_ring[self._obs_next % len(self._obs_ring)]
-        self._obs_next += 1
+        if copy:
+            # a fresh (pageable) array per step: the library lands the transfer in a pinned buffer of the handle piece by piece
+            # and copies each piece here while the next ones are still on the link (fleet_step_host)
+            obs = np.empty((self.E, self.obs_dim), dtype=np.float32)
+        else:
+            if len(self._obs_ring) < self.OBS_RING:
+                self._obs_ring.append(self.pinned_array((self.E, self.obs_dim)))
+            obs = self._obs_ring[self._obs_next % len(self._obs_ring)]
+            self._obs_next += 1
         if obs.shape != (self.E, self.obs_dim) or obs.dtype != np.float32:  # what fleet_step_host will write
             raise FleetHipError(_capi.ERR_INVALID, "internal: observation buffer of the wrong shape")
         if self._term is None:  # reused across steps: only the rows of envs that just finished are meaningful
@@ -250,7 +255,7 @@ class FleetBatch:
         done = np.empty(self.E, dtype=np.uint8)
         self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,
                                               done.ctypes.data, term.ctypes.data))
-        return (obs.copy() if copy else obs), rew, done, term
+        return obs, rew, done, term
 
     def last_step_episodes(self):
         """(env indices, returns, lengths) of the episodes that ended in the last `step()` -- already on the host, no launch."""

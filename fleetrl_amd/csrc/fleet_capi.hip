@@ -8,11 +8,18 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is opened at run time (fleet_rccl_*), nothing links against it
 
+#include <unistd.h>
+
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fleet_device.h"
@@ -20,6 +27,56 @@
 namespace {
 
 thread_local std::string g_create_error;
+
+// Host-side copies of the host-pointer path (observations from the pinned landing buffer to a pageable destination): one core
+// reads memory the device has just written at ~20 GB/s, so the pieces of a transfer are copied by a few worker threads while
+// the calling thread waits for the next piece to land.  One pool per process, created at the first use and never torn down
+// (its threads sleep on a condition variable); a forked child makes its own.
+class CopyPool {
+ public:
+  static CopyPool* get() {
+    static std::mutex mk;
+    static CopyPool* pool = nullptr;
+    std::lock_guard<std::mutex> g(mk);
+    if (!pool || pool->pid_ != getpid()) pool = new CopyPool(3);  // (a fork leaves the parent's object behind: no threads in it)
+    return pool;
+  }
+  void submit(void* dst, const void* src, size_t n) {
+    pending_.fetch_add(1, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      q_.push_back({dst, src, n});
+    }
+    cv_.notify_one();
+  }
+  void wait() {  // all submitted copies done (the caller's own: calls on one handle are serialised, pools are per process)
+    while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+
+ private:
+  struct Task { void* dst; const void* src; size_t n; };
+  explicit CopyPool(int workers) : pid_(getpid()) {
+    for (int i = 0; i < workers; ++i) std::thread([this] { run(); }).detach();
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !q_.empty(); });
+        t = q_.front();
+        q_.pop_front();
+      }
+      memcpy(t.dst, t.src, t.n);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  pid_t pid_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<Task> q_;
+  std::atomic<int> pending_{0};
+};
 
 struct Batch {
   FleetParams p{};
@@ -45,6 +102,10 @@ struct Batch {
   char* pin_small = nullptr;
   void* pin_actions = nullptr;
   float* pin_term = nullptr;
+  // observations to a pageable destination: pinned landing buffer (allocated at the first such step) + one event per piece
+  char* pin_obs = nullptr;
+  static constexpr int kObsPieces = 3;  // every transfer on the link costs ~15 us of its own: 8 pieces halve the link rate (measured)
+  hipEvent_t obs_piece_ev[kObsPieces] = {};
   bool host_step_has_episodes = false;
   uint32_t last_step_err = 0;  // OR of the device error bits as of the last fleet_step_host
   double* st_dist = nullptr;
@@ -574,8 +635,10 @@ int fleet_destroy(fleet_handle h) {
   (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   for (void* ptr : h->allocs) (void)hipFree(ptr);
-  for (void* ptr : {(void*)h->pin_small, h->pin_actions, (void*)h->pin_term})
+  for (void* ptr : {(void*)h->pin_small, h->pin_actions, (void*)h->pin_term, (void*)h->pin_obs})
     if (ptr) (void)hipHostFree(ptr);
+  for (auto& e : h->obs_piece_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->dev_sched) (void)hipFree(h->dev_sched);
   for (auto& e : h->region_events)
     if (e) (void)hipEventDestroy(e);
@@ -784,10 +847,53 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
                                          reinterpret_cast<int32_t*>(h->st_small + h->small_off_len), h->st_term_compact, h->stream));
   h->host_step_has_episodes = terminal_obs != nullptr;
   HIP_TRY(h, hipMemcpyAsync(h->pin_small, h->st_small, h->small_bytes, hipMemcpyDeviceToHost, h->stream));
-  // the observations go straight to the caller's buffer: at the link rate if it is pinned, through the runtime's chunked
-  // staging otherwise (measured faster than one pinned mirror + a 6 MB memcpy on the host)
-  HIP_TRY(h, hipMemcpyAsync(obs, h->st_obs, OD, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // The observations: straight into the caller's buffer at the link rate if it is pinned.  A pageable destination (a fresh
+  // array per step, what the reference's env returns) gets them in pieces through a pinned landing buffer of the handle: each
+  // piece is copied to its destination by this thread as soon as it has landed, while the following pieces are still on the
+  // link -- the host copy (the slower of the two at 6 MB per step) hides the transfer instead of following it.
+  const bool obs_pinned = pinned(obs);
+  (void)hipGetLastError();
+  if (obs_pinned || OD < (size_t)1 << 18) {
+    HIP_TRY(h, hipMemcpyAsync(obs, h->st_obs, OD, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  } else {
+    if (!h->pin_obs) {
+      HIP_TRY(h, hipHostMalloc((void**)&h->pin_obs, OD, hipHostMallocDefault));
+      for (auto& e : h->obs_piece_ev) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    // the first piece is small (the host copy starts early), the rest equal; boundaries on 4 KiB
+    size_t cut[Batch::kObsPieces + 1];
+    constexpr int P = Batch::kObsPieces;
+    cut[0] = 0;
+    const size_t first = (OD / (2 * (size_t)P)) & ~(size_t)4095;
+    for (int c = 1; c < P; ++c) cut[c] = (first + (OD - first) * (size_t)(c - 1) / (size_t)(P - 1)) & ~(size_t)4095;
+    cut[P] = OD;
+    const char* src = reinterpret_cast<const char*>(h->st_obs);
+    for (int c = 0; c < P; ++c) {
+      if (cut[c + 1] > cut[c])
+        HIP_TRY(h, hipMemcpyAsync(h->pin_obs + cut[c], src + cut[c], cut[c + 1] - cut[c], hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipEventRecord(h->obs_piece_ev[c], h->stream));
+    }
+    char* dst = reinterpret_cast<char*>(obs);
+    CopyPool* pool = CopyPool::get();
+    hipError_t werr = hipSuccess;
+    constexpr int kSplit = 4;  // host copies per piece: three workers + (for the last piece) this thread
+    for (int c = 0; c < P && werr == hipSuccess; ++c) {
+      werr = hipEventSynchronize(h->obs_piece_ev[c]);
+      if (werr != hipSuccess || cut[c + 1] <= cut[c]) continue;
+      const size_t lo = cut[c], n = cut[c + 1] - cut[c];
+      const bool last = (c + 1 == P);
+      const int parts = last ? kSplit : kSplit - 1;
+      for (int k = 0; k < parts; ++k) {
+        const size_t a0 = lo + ((n * (size_t)k / parts) & ~(size_t)63);
+        const size_t a1 = (k + 1 == parts) ? lo + n : lo + ((n * (size_t)(k + 1) / parts) & ~(size_t)63);
+        if (last && k + 1 == parts) memcpy(dst + a0, h->pin_obs + a0, a1 - a0);  // nothing left to wait for: this thread copies too
+        else pool->submit(dst + a0, h->pin_obs + a0, a1 - a0);
+      }
+    }
+    pool->wait();
+    HIP_TRY(h, werr);
+  }
   memcpy(reward, h->pin_small, (size_t)E * 8);
   memcpy(done, h->pin_small + h->small_off_done, (size_t)E);
   h->last_step_err = *reinterpret_cast<const uint32_t*>(h->pin_small + h->small_off_count + 4);  // came with the rewards

@@ -246,7 +246,10 @@ int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minut
 
 /* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);
-/* terminal_obs (or NULL): rows of envs that finished in this step are written; all other rows are left untouched */
+/* terminal_obs (or NULL): rows of envs that finished in this step are written; all other rows are left untouched.
+ * `obs` / `actions` may be any host memory: buffers from fleet_host_alloc (pinned) are transferred to / from directly; a
+ * pageable `obs` receives the observations in pieces through a pinned buffer of the handle, each piece copied to it while
+ * the next ones are still on the link. */
 int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward,
                     uint8_t* done, float* terminal_obs);
 

@@ -332,3 +332,34 @@ def test_drop_in_classes_under_installed_gymnasium_and_sb3_base_classes():
             mod = sys.modules.get(f"fleetrl_amd.{attr}")
             if mod is not None:
                 setattr(fleetrl_amd, attr, mod)
+
+
+def test_fresh_observation_arrays_equal_the_pinned_ring_buffers():
+    """`copy_obs=True` (default; a fresh pageable array per step, like the reference's env) takes the pipelined route of
+    fleet_step_host -- pieces on the link through a pinned landing buffer, copied out by worker threads -- and must deliver the
+    very bytes the direct transfer into a pinned buffer (`copy_obs=False`) does; sized above the 256 KiB below which the
+    transfer is not split, with an odd row count so that the pieces do not end on row boundaries."""
+    from fleetrl_amd import FleetVecEnv
+    from fleetrl_amd.synth import synth_tables
+    from test_hip_shapes import _cfg
+
+    N, E = 50, 333
+    tb = synth_tables("ct", N, seed=77)
+    fresh = FleetVecEnv(_cfg("ct", "rainflow", False), E, tables=tb, seed=5)
+    ring = FleetVecEnv(_cfg("ct", "rainflow", False), E, tables=tb, seed=5, copy_obs=False)
+    assert E * fresh.observation_space.shape[0] * 4 > (1 << 18)
+    np.testing.assert_array_equal(fresh.reset(), ring.reset())
+    rng = np.random.default_rng(1)
+    kept = []
+    for k in range(120):  # 24 h episodes: across an auto-reset
+        a = rng.uniform(-1, 1, size=(E, N)).astype(np.float32)
+        o1, r1, d1, i1 = fresh.step(a)
+        o2, r2, d2, i2 = ring.step(a)
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_array_equal(d1, d2)
+        kept.append((o1, o2.copy()))
+    for o1, o2 in kept[-8:]:  # the fresh arrays are private: later steps did not touch them
+        np.testing.assert_array_equal(o1, o2)
+    fresh.close()
+    ring.close()
