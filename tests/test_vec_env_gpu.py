@@ -363,3 +363,37 @@ def test_fresh_observation_arrays_equal_the_pinned_ring_buffers():
         np.testing.assert_array_equal(o1, o2)
     fresh.close()
     ring.close()
+
+
+def test_two_vec_envs_stepped_from_two_threads_share_the_copy_workers():
+    """The host-pointer path's copy workers are one pool per process: two handles stepped concurrently from two Python threads
+    (ctypes releases the GIL inside fleet_step_host) must each get their own observations, equal to the same envs stepped alone."""
+    import threading
+
+    from fleetrl_amd import FleetVecEnv
+    from fleetrl_amd.synth import synth_tables
+    from test_hip_shapes import _cfg
+
+    N, E, steps = 50, 300, 40
+    tbs = [synth_tables("ct", N, seed=81), synth_tables("ut", N, seed=82)]
+    cfgs = [_cfg("ct", "rainflow", False), _cfg("ut", "rainflow", True)]
+    acts = [np.random.default_rng(3 + k).uniform(-1, 1, size=(steps, E, N)).astype(np.float32) for k in range(2)]
+
+    def rollout(k, out):
+        env = FleetVecEnv(cfgs[k], E, tables=tbs[k], seed=9)
+        obs = [env.reset()]
+        for a in acts[k]:
+            obs.append(env.step(a)[0])
+        env.close()
+        out[k] = np.stack(obs)
+
+    alone, together = {}, {}
+    for k in range(2):
+        rollout(k, alone)
+    th = [threading.Thread(target=rollout, args=(k, together)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        np.testing.assert_array_equal(together[k], alone[k])
