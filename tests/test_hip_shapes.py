@@ -155,6 +155,36 @@ def test_real_time_event_skipping_matches_oracle(uc, n_evs, num_envs, deg, norm)
     _compare(uc, n_evs, num_envs, deg, norm, steps=260 if n_evs < 100 else 150, seed=11, real_time=True)
 
 
+def test_full_headline_batch_equals_its_eight_shards():
+    """The multi-GPU layout at BASELINE's full size, on one GPU: the 4096 x 50 batch against the eight 512-env shards an 8-GPU
+    run would hold (contiguous env ranges, env_id_offset = first global env id, same seed), 48 h episodes stepped over an episode
+    end -- observations, rewards, dones and the degradation state bit-identical, i.e. no result depends on which envs share a
+    launch (weak scaling needs no data-path collective)."""
+    from fleetrl_amd.batch import FleetBatch
+
+    tb = _tables("ct", 50)
+    rc = resolve_config(_cfg("ct", "rainflow", False, episode_length=48))
+    tf = time_features(tb)
+    E, S = 4096, 8
+    whole = FleetBatch(make_params(rc, tb, E, seed=5), tb, tf)
+    shards = [FleetBatch(make_params(rc, tb, E // S, seed=5, env_id_offset=k * (E // S)), tb, tf) for k in range(S)]
+    np.testing.assert_array_equal(whole.reset(), np.concatenate([b.reset() for b in shards]))
+    rng = np.random.default_rng(10)
+    for s in range(200):
+        a = rng.uniform(-1, 1, size=(E, 50)).astype(np.float32)
+        a[rng.random((E, 50)) < 0.15] = 0.0
+        ow, rw, dw, _ = whole.step(a)
+        parts = [b.step(a[k * (E // S):(k + 1) * (E // S)]) for k, b in enumerate(shards)]
+        np.testing.assert_array_equal(ow, np.concatenate([p[0] for p in parts]), err_msg=f"obs, step {s}")
+        np.testing.assert_array_equal(rw, np.concatenate([p[1] for p in parts]), err_msg=f"reward, step {s}")
+        np.testing.assert_array_equal(dw, np.concatenate([p[2] for p in parts]), err_msg=f"done, step {s}")
+    for name in ("soc", "soh", "fd_cyc", "rf_len", "time_idx", "last_ep_return", "episodes"):
+        np.testing.assert_array_equal(whole.get(name), np.concatenate([b.get(name) for b in shards]), err_msg=name)
+    assert whole.get("episodes").min() >= 1
+    for b in [whole] + shards:
+        b.close()
+
+
 def test_headline_size_full_batch():
     """BASELINE.json configs[2] at its FULL size and as bench.py runs it -- 4096 envs x 50 EVs, caretaker fleet, load+pv,
     rainflow, 48 h episodes -- HIP against the oracle over two whole episodes and into the third (quirk Q6: rainflow_length /
