@@ -185,6 +185,69 @@ def test_full_headline_batch_equals_its_eight_shards():
         b.close()
 
 
+def test_k_steps_per_launch_equal_single_steps_at_full_size():
+    """Size-independent property at BASELINE's full size: K steps in one launch (`fleet_step_many_dev`, the kernel that carries
+    the rainflow row head in registers) leave the 4096 x 50 batch in exactly the state K single-step launches do -- state fields
+    bit-identical, reward sums to the last place of a re-associated sum -- over episode ends and daily degradation rows, and a
+    device-side policy rollout equals the same policy's actions fed step by step."""
+    import torch
+
+    from fleetrl_amd import _capi
+    from fleetrl_amd.batch import FleetBatch
+
+    tb = _tables("ct", 50)
+    rc = resolve_config(_cfg("ct", "rainflow", False, episode_length=48))
+    tf = time_features(tb)
+    E, N = 4096, 50
+    many, single = FleetBatch(make_params(rc, tb, E, seed=7), tb, tf), FleetBatch(make_params(rc, tb, E, seed=7), tb, tf)
+    np.testing.assert_array_equal(many.reset(), single.reset())
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    obs = torch.empty((E, many.obs_dim), device=dev)
+    obs1 = torch.empty_like(obs)
+    rs = torch.empty(E, device=dev, dtype=torch.float64)
+    r1 = torch.empty(E, device=dev, dtype=torch.float64)
+    d1 = torch.empty(E, device=dev, dtype=torch.uint8)
+    dc = torch.empty(E, device=dev, dtype=torch.int32)
+    fields = ("soc", "soh", "hours_left", "fd_cyc", "sei_l", "rf_len", "time_idx", "episodes", "ep_return", "last_ep_return")
+    for launch, K in enumerate((64, 96, 61)):  # 221 steps: past the end of the 192-step episodes
+        tape = torch.rand((K, E, N), device=dev, generator=gen) * 2 - 1
+        tape[torch.rand((K, E, N), device=dev, generator=gen) < 0.15] = 0.0
+        want_r = torch.zeros(E, device=dev, dtype=torch.float64)
+        want_d = torch.zeros(E, device=dev, dtype=torch.int32)
+        torch.cuda.synchronize()  # the handles launch on streams of their own: torch's work on the tape must be done
+        many.step_many_dev(K, tape.data_ptr(), obs.data_ptr(), rs.data_ptr(), dc.data_ptr())
+        for k in range(K):
+            single.step_dev(tape[k].data_ptr(), obs1.data_ptr(), r1.data_ptr(), d1.data_ptr())
+            single.synchronize()
+            want_r += r1
+            want_d += d1.to(torch.int32)
+        many.synchronize()
+        assert torch.equal(dc, want_d), f"episode ends, launch {launch}"
+        torch.testing.assert_close(rs, want_r, rtol=1e-12, atol=1e-9)
+        assert torch.equal(obs, obs1), f"last observation, launch {launch}"
+        for name in fields:
+            np.testing.assert_array_equal(many.get(name), single.get(name), err_msg=f"{name} after launch {launch}")
+    assert many.get("episodes").min() >= 1
+    # device-side policy ("distributed": clip(get_dist_factor(), 0, 1)) against its own actions fed one step at a time
+    K = 48
+    act = torch.empty((E, N), device=dev, dtype=torch.float64)
+    many.rollout_policy_dev(_capi.POLICY_DISTRIBUTED, K, obs.data_ptr(), rs.data_ptr(), dc.data_ptr())
+    for k in range(K):
+        act.copy_(torch.from_numpy(np.clip(single.dist_factor(), 0.0, 1.0)))
+        torch.cuda.synchronize()
+        single.step_dev(act.data_ptr(), obs1.data_ptr(), r1.data_ptr(), d1.data_ptr(), act_dtype=_capi.ACT_F64)
+        single.synchronize()
+    many.synchronize()
+    assert torch.equal(obs, obs1), "last observation of the policy rollout"
+    for name in fields:
+        np.testing.assert_array_equal(many.get(name), single.get(name), err_msg=f"{name} after the policy rollout")
+    many.check_errors()
+    single.check_errors()
+    many.close()
+    single.close()
+
+
 def test_headline_size_full_batch():
     """BASELINE.json configs[2] at its FULL size and as bench.py runs it -- 4096 envs x 50 EVs, caretaker fleet, load+pv,
     rainflow, 48 h episodes -- HIP against the oracle over two whole episodes and into the third (quirk Q6: rainflow_length /
