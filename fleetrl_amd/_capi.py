@@ -19,7 +19,7 @@ PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
 POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
-DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END = 1, 2, 4, 8, 16
+DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL = 1, 2, 4, 8, 16, 32
 
 # fleet_get fields: name -> (id, dtype, per_car)
 FIELDS = {

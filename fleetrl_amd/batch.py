@@ -97,7 +97,9 @@ class FleetBatch:
         e = int(np.flatnonzero(bits_all)[0])
         bits = int(bits_all[e])
         where = f"env {e} (global env {e + int(self.params.env_id_offset)}), table row {int(rows[e])} of {int(self.params.table_rows)}"
-        if bits & _capi.DEVERR_OBS_FORMAT:
+        if bits & _capi.DEVERR_INTERNAL:
+            exc = FleetHipError(_capi.ERR_STATE, f"internal error of the library (inconsistent launch arguments): {where}")
+        elif bits & _capi.DEVERR_OBS_FORMAT:
             exc = TypeError("Observation format not recognized")
         elif bits & _capi.DEVERR_DOD_RANGE:
             exc = TypeError("DoD too large.")

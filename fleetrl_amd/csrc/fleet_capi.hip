@@ -551,7 +551,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
 // Name the first env that carries device error bits (the reference raises at the offending line: fleet_environment.py:610,
 // rainflow_sei_degradation.py:164-167,179-180,209-210; running off the table is a KeyError of its `db.loc[...]`).
 const char* deverr_names(uint32_t bits, char* buf, size_t n) {
-  snprintf(buf, n, "%s%s%s%s%s", (bits & FLEET_DEVERR_OBS_FORMAT) ? " observation format not recognized;" : "",
+  snprintf(buf, n, "%s%s%s%s%s%s", (bits & FLEET_DEVERR_INTERNAL) ? " internal: inconsistent launch arguments;" : "",
+           (bits & FLEET_DEVERR_OBS_FORMAT) ? " observation format not recognized;" : "",
            (bits & FLEET_DEVERR_NEG_LIFE) ? " life degradation is negative;" : "",
            (bits & FLEET_DEVERR_SOH_MISMATCH) ? " degradation calculation is not correct;" : "",
            (bits & FLEET_DEVERR_DOD_RANGE) ? " DoD too large;" : "",

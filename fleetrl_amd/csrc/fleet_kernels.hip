@@ -781,12 +781,30 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // block, so that those loads do not wait for an argument fetch.
     // (no __restrict__ on the state pointers: the same kernel stores to these arrays through the argument block)
     const Hot* p_hot, const SegRec* p_run, const double* p_soh, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* p_env,
-    FleetDev d, const void* __restrict__ actions, int act_mode, int K,
+    FleetDev d_arg, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
                                                                int32_t* __restrict__ done_count) {
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
+  // The argument block is ~150 dwords of scalars for ~100 scalar registers.  One step per launch, one EV per lane: what the END
+  // of the step needs of it (the tail store's geometry, the leader lane's constants and pointers, the head bookkeeping) is
+  // re-read from the kernel-argument segment after the lane's EV is done -- scalar loads through the constant cache, behind a
+  // laundered pointer so that they are not hoisted back to the entry -- instead of being fetched at entry and carried over the
+  // whole step in lanes of a vector register (24 v_writelane + 22 v_readlane on every wavefront's path before; none now).
+  // Re-reading in the MIDDLE of the EV's step instead stalls on those loads (+0.3 us at 2048 envs) and re-reading everything at
+  // several points costs +0.7 us (profiles/r04_experiments/args_reloaded_*).  `late_args_ok` guards the hard-wired offset.
+  const FleetDev& d = d_arg;
+  auto late_args = [&]() -> const FleetDev& {
+    if constexpr (!MULTI && !WIDE) {
+      typedef const __attribute__((address_space(4))) char* karg_ptr;
+      karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + 48;  // p_hot .. p_env: 4 x 8 + 2 x 4 + 8 bytes
+      asm volatile("" : "+s"(kp));
+      return *(const FleetDev*)(const __attribute__((address_space(4))) FleetDev*)kp;
+    } else {
+      return d_arg;
+    }
+  };
   const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -1125,6 +1143,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
                            top_c, kRfCarry);
       if (!WIDE) break;  // N <= G: a single pass, and no loop for the compiler to hoist rare-path constants out of
     }
+    {  // ---- the rest of the step reads the argument block afresh (see `late_args`) ----
+    const FleetDev& d = late_args();
+    if (!MULTI && !WIDE && (d.T != d_arg.T || d.E != p_E)) err |= FLEET_DEVERR_INTERNAL;  // the block is not where it is assumed to be
     if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
     if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
@@ -1236,8 +1257,11 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const bool minute15 = ((hm1 & 255) == 15) && !(hm1 & 0x8000);  // minute == 15 and second == 0
       if (group_any<G>(ev_lane) || is_done || minute15 || (t + 1 > d.T - 1)) break;
     }
+    }  // late_args scope
   }
 
+  {  // ---- after the steps: again through the freshly read block ----
+  const FleetDev& d = late_args();
   // (only where a single-step launch can follow on the same handle: with more EVs than lanes every kernel reads the table)
   if (!kEarly && !WIDE && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
     const int rn = r.t + 1 > d.T - 1 ? d.T - 1 : r.t + 1;
@@ -1265,6 +1289,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     atomicOr(&d.env[e].err, err);
     atomicOr(d.self->err_any, err);
   }
+  }  // late_args scope
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
 }

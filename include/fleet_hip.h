@@ -63,6 +63,7 @@ extern "C" {
 #define FLEET_DEVERR_SOH_MISMATCH 4u   /* "Degradation calculation is not correct" :209-210                         */
 #define FLEET_DEVERR_DOD_RANGE 8u      /* "DoD too large" :164-167                                                   */
 #define FLEET_DEVERR_TABLE_END 16u     /* episode ran past the last table row                                        */
+#define FLEET_DEVERR_INTERNAL 32u      /* a kernel found its launch arguments inconsistent (a build problem, not a data one) */
 
 /*
  * Scalars of one env group (all envs of a handle share tables and parameters).
