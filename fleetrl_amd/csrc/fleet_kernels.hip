@@ -23,8 +23,9 @@
 // the row it advances to -- travels with the state (`run`, struct SegRec in fleet_device.h): a lane holds the record of row
 // t+1 when the launch starts, so nothing it needs to start its arithmetic depends on the env's time row, and it only touches
 // the table when row t+2 crosses a schedule event of its EV (about 4 % of the EV-steps), for the NEXT launch.  The row
-// flags the state machine needs travel in the env head; the physics record of the time row and the pre-assembled auxiliary
-// observation slots are requested when the head arrives and consumed late (money terms, observation stores).
+// flags the state machine needs travel in the env head; the physics record of the time row is requested when the head
+// arrives and consumed late (money terms); the four table-derived auxiliary observation slots are computed per lane from the
+// carried record (one reciprocal, no division; write_obs_ev).
 //
 // Rainflow without a history replay.  The reference re-runs rainflow over the whole episode history every
 // simulated day.  Three-point rainflow is a streaming algorithm, so the kernel keeps its state per EV (a row in HBM:
