@@ -361,30 +361,44 @@ def main():
     if args.gather == "capi" and launched and args.backend == "nccl" and len(groups) == 1:
         # the same gather without PyTorch's collectives: rank 0 makes the RCCL id, the launcher's store hands it round, every rank
         # creates its communicator and the library issues one ncclAllGather on the handle's stream
+        # Every stage is agreed on by ALL ranks before anybody acts on it (an all_reduce(MIN) of an ok flag): a rank that failed
+        # alone would otherwise sit in the torch gather while the others sit in ncclAllGather.
+        import ctypes as C
+
+        from fleetrl_amd import _capi
+
+        def all_ok(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], device=cdev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        lib = groups[0].batch.lib
+        comm = C.c_void_p()
+        why = None
         try:
-            import ctypes as C
-
-            from fleetrl_amd import _capi
-
-            lib = groups[0].batch.lib
             uid = (C.c_char * 128)()
+            ok = True
             if rank == 0 and lib.fleet_rccl_unique_id(uid) != _capi.OK:
-                raise RuntimeError(lib.fleet_last_error(None).decode())
-            box = [bytes(uid)]
+                ok, why = False, lib.fleet_last_error(None).decode()
+            box = [bytes(uid) if ok else None]
             dist.broadcast_object_list(box, src=0)
-            comm = C.c_void_p()
-            if lib.fleet_rccl_comm_create(local_rank, world, rank, box[0], C.byref(comm)) != _capi.OK:
-                raise RuntimeError(lib.fleet_last_error(None).decode())
-            out = torch.zeros((world, 2, E), device=dev, dtype=torch.float64)
-            if lib.fleet_gather_episode_stats_rccl(groups[0].batch.h, comm, world, C.c_void_p(out.data_ptr())) != _capi.OK:
-                raise RuntimeError(lib.fleet_last_error(groups[0].batch.h).decode())
-            sync()
-            r_all, n_all = out[:, 0, :].reshape(-1), out[:, 1, :].reshape(-1).to(torch.int32)
-            lib.fleet_rccl_comm_destroy(comm)
-            gather_how = "fleet_gather_episode_stats_rccl: one ncclAllGather issued by the C ABI"
-        except Exception as exc:  # noqa: BLE001 - a logging path must not cost the run its result
-            gather_how = f"torch.distributed all_gather_into_tensor (the C-ABI gather failed: {exc})"
-            r_all = None
+            ok = box[0] is not None
+            if ok and lib.fleet_rccl_comm_create(local_rank, world, rank, box[0], C.byref(comm)) != _capi.OK:
+                ok, why = False, lib.fleet_last_error(None).decode()
+            if all_ok(ok):  # every rank holds a communicator: the collective can be entered
+                out = torch.zeros((world, 2, E), device=dev, dtype=torch.float64)
+                ok = lib.fleet_gather_episode_stats_rccl(groups[0].batch.h, comm, world, C.c_void_p(out.data_ptr())) == _capi.OK
+                if not ok:
+                    why = lib.fleet_last_error(groups[0].batch.h).decode()
+                sync()
+                if all_ok(ok):
+                    r_all, n_all = out[:, 0, :].reshape(-1), out[:, 1, :].reshape(-1).to(torch.int32)
+                    gather_how = "fleet_gather_episode_stats_rccl: one ncclAllGather issued by the C ABI"
+            if r_all is None:
+                gather_how = f"torch.distributed all_gather_into_tensor (the C-ABI gather failed on some rank: {why or 'another rank'})"
+        finally:
+            if comm:
+                lib.fleet_rccl_comm_destroy(comm)
     if r_all is None:
         r_all, n_all = gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)
     barrier()

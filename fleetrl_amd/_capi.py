@@ -213,6 +213,9 @@ def load_library():
     lib.fleet_rccl_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.fleet_rccl_comm_destroy.argtypes = [vp]
     lib.fleet_gather_episode_stats_rccl.argtypes = [vp, vp, C.c_int, vp]
+    if hasattr(lib, "fleet_selftest_division"):  # (absent from the round-4 library the A/B scripts run beside the tree's)
+        lib.fleet_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        lib.fleet_selftest_division.restype = C.c_int
     for name in ("fleet_create", "fleet_destroy", "fleet_set_stream", "fleet_get_stream", "fleet_use_own_stream", "fleet_log_dropped",
                  "fleet_log_capacity", "fleet_log_read",
                  "fleet_log_clear", "fleet_synchronize", "fleet_set_start_schedule",
@@ -236,5 +239,5 @@ EXPORTED_SYMBOLS = (
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
-    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl",
+    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division",
 )

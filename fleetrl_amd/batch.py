@@ -52,8 +52,11 @@ class _PinnedBuffer:
     @classmethod
     def drain(cls):
         """Free the parked blocks (called on the caller's thread, never from a finaliser)."""
-        while cls._dead:
-            lib, addr = cls._dead.pop()
+        while True:  # several vec envs may be stepped from several threads: `pop` is atomic, emptiness is not a promise
+            try:
+                lib, addr = cls._dead.pop()
+            except IndexError:
+                break
             lib.fleet_host_free(C.c_void_p(addr))
 
 
@@ -76,8 +79,11 @@ class FleetBatch:
         self._obs_next = 0     # mixed with the caller's pinned_array() buffers)
 
     # ------------------------------------------------------------------------------------------------------
-    def _check(self, rc: int):
-        if rc == _capi.ERR_STATE:
+    def _check(self, rc: int, device_errors: bool = False):
+        """`device_errors`: the call is one that reports the kernels' FLEET_DEVERR_* bits through FLEET_ERR_STATE (the host step,
+        fleet_check_errors): map them to the reference's exception types.  Any other entry's ERR_STATE (a timer read before its
+        start, a log that is off, ...) is an error of the call itself, whatever sticky device bits an env may carry."""
+        if rc == _capi.ERR_STATE and device_errors:
             self._raise_device_error()
         if rc != _capi.OK:
             raise FleetHipError(rc, self.lib.fleet_last_error(self.h).decode())
@@ -256,7 +262,7 @@ class FleetBatch:
         rew = np.empty(self.E)
         done = np.empty(self.E, dtype=np.uint8)
         self._check(self.lib.fleet_step_host(self.h, a.ctypes.data, dt, obs.ctypes.data, rew.ctypes.data,
-                                              done.ctypes.data, term.ctypes.data))
+                                              done.ctypes.data, term.ctypes.data), device_errors=True)
         return obs, rew, done, term
 
     def last_step_episodes(self):
@@ -349,7 +355,7 @@ class FleetBatch:
 
     def check_errors(self):
         """Raise if any env carries device error bits (see _raise_device_error); `step()` does this by itself."""
-        self._check(self.lib.fleet_check_errors(self.h))
+        self._check(self.lib.fleet_check_errors(self.h), device_errors=True)
 
     def last_step_error_bits(self) -> int:
         """OR of all envs' device error bits as of the last `step()` (already on the host)."""

@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the library is opened at run time (fleet_rccl_*), nothing links against it
 
 #include <unistd.h>
 
@@ -17,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -422,6 +422,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.max_time_left = p->max_time_left;
   // auxiliary observation slots: divisions by constants become multiplications by the correctly rounded quotient / reciprocal
   d.hn_scale = p->batt_cap_nominal / (p->evse_power * p->charging_eff);
+  d.inv_eta_c = 1.0 / p->charging_eff;
 
   FleetCold& cd = b->cold_host;
   cd.min_laxity = p->min_laxity; cd.def_soc = p->def_soc; cd.init_soh = p->init_soh; cd.temperature = p->temperature;
@@ -496,7 +497,12 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
       b->error = "num_cars x episode length: the rainflow rows of one env exceed 4 GiB";
       return FLEET_ERR_INVALID;
     }
+#ifdef FLEET_EXP_RFSTRIDE  // TIMING EXPERIMENT ONLY (rows overlap: results are wrong on purpose)
+    d.rf_row_stride = FLEET_EXP_RFSTRIDE;
+    if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride + (size_t)d.stack_cap + 64, false))) return rc;
+#else
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
+#endif
     // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
@@ -561,7 +567,15 @@ const char* deverr_names(uint32_t bits, char* buf, size_t n) {
 }
 
 // RCCL, bound at run time: a process that never gathers across GPUs does not need librccl, and a process that has PyTorch in
-// it gets the copy PyTorch has already mapped (same soname) instead of a second one.
+// it gets the copy PyTorch has already mapped (same soname) instead of a second one.  The handful of NCCL-API declarations the
+// binding needs are restated here (their ABI is fixed: rccl/rccl.h `ncclUniqueId` = 128 opaque bytes, `ncclSuccess` = 0,
+// `ncclDouble` = 8), so that building this library does not need RCCL's headers either.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[FLEET_RCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclDouble = 8;
 struct RcclApi {
   void* lib = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -571,16 +585,22 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
-RcclApi& rccl() {
+void rccl_bind(RcclApi& api);
+RcclApi& rccl() {  // bound once, whichever thread asks first
   static RcclApi api;
-  if (api.lib || !api.why.empty()) return api;
+  static std::once_flag once;
+  std::call_once(once, rccl_bind, std::ref(api));
+  return api;
+}
+void rccl_bind(RcclApi& api) {
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
     api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (api.lib) break;
   }
   if (!api.lib) {
-    api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
-    return api;
+    const char* e = dlerror();
+    api.why = std::string("librccl not found: ") + (e ? e : "");
+    return;
   }
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
@@ -588,7 +608,6 @@ RcclApi& rccl() {
   api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.why = "librccl lacks an expected symbol";
-  return api;
 }
 
 void drop_graph(Batch* b) {
@@ -1259,3 +1278,22 @@ int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_l
 }
 
 }  // extern "C"
+
+int fleet_selftest_division(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
+  if (!mismatches || n_pairs == 0) return FLEET_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLEET_ERR_NODEVICE;
+  if (device < 0 || device >= ndev) return FLEET_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return FLEET_ERR_HIP;
+  unsigned long long* bad = nullptr;
+  if (hipMalloc(&bad, 2 * sizeof(unsigned long long)) != hipSuccess) return FLEET_ERR_HIP;
+  int rc = FLEET_OK;
+  unsigned long long host[2] = {0, 0};
+  if (hipMemset(bad, 0, sizeof host) != hipSuccess || fleet_launch_selftest_division(n_pairs, seed, bad, nullptr) != hipSuccess ||
+      hipMemcpy(host, bad, sizeof host, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = FLEET_ERR_HIP;
+  (void)hipFree(bad);
+  mismatches[0] = host[0];
+  mismatches[1] = host[1];
+  return rc;
+}

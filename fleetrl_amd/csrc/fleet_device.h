@@ -206,6 +206,7 @@ struct FleetDev {
   // auxiliary observation slots (observer_*.py:85-91), computed per lane from the carried schedule record:
   // hn_scale = nominal capacity / (evse * eta_c); the normaliser's reciprocals are in FleetCold
   double hn_scale;
+  double inv_eta_c;  // 1 / eta_c, correctly rounded (host): `need / eta_c` as div_rcp (fleet_kernels.hip)
   // ---- read-only tables ---------------------------------------------------------------------------------
   const SegRec* seg;          // [T,N] schedule records in run-length form
   const PhysRow* tab_phys;    // [T]
@@ -250,3 +251,5 @@ hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, con
 hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t s);
 // unpack state planes for fleet_get: field ids of include/fleet_hip.h -> contiguous device buffer `out`
 hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s);
+// div_rcp (the charge arithmetic's divisions by a reciprocal) against the IEEE sequence on n random operand pairs: bad_dev[0..1]
+hipError_t fleet_launch_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* bad_dev, hipStream_t s);

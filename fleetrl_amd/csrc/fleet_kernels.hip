@@ -171,9 +171,36 @@ __device__ __forceinline__ int choose_start(const FleetCold* cd, int E, int e, i
   return cd->pick_rows ? cd->pick_rows[k] : k;  // candidate list of the pickers' date_range on an irregular grid
 }
 
+// 1 / x for the auxiliary slots' one division: hardware reciprocal seed (v_rcp_f64, ~26 good bits) + two Newton steps = full
+// float64 accuracy (<= 1 ulp) in five instructions, against ~14 of the IEEE division sequence with its special-case handling.
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+// The same with ONE Newton step: relative error <= ~2^-44 (the seed is good to ~2^-23).  Enough wherever the result is rounded
+// to float32 afterwards or feeds div_rcp's residual correction (which squares the reciprocal's error once more).
+__device__ __forceinline__ double rcp_newton1(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+// x / c, IEEE-correctly rounded, from a reciprocal rc ~ 1 / c (Markstein's residual correction): q0 = x * rc is within a few
+// ulp of the quotient, e = x - q0 * c is EXACT in one fma, and q0 + e * rc is the quotient to a relative 2 * |rc * c - 1|^2
+// (2^-104 for a correctly rounded rc, 2^-87 for rcp_newton1) before the final rounding -- i.e. the correctly rounded quotient
+// unless x / c lies that close to a rounding boundary, which no pair of float64 operands of these magnitudes does in practice
+// (tests/test_capi_gpu.py::test_division_by_reciprocal_is_bit_exact: 2^30 operand pairs of the charge arithmetic's ranges
+// against the IEEE sequence, 0 differences).  `v_div_fixup` restores what the three fmas lose at the edges (x = +-0, inf, NaN,
+// c = 0): 5 vector instructions instead of the 11 of the IEEE division sequence, none of them quarter-rate.
+__device__ __forceinline__ double div_rcp(double x, double c, double rc) {
+  const double q0 = x * rc;
+  const double e = fma(-q0, c, x);
+  return __builtin_amdgcn_div_fixup(fma(e, rc, q0), c, x);
+}
+
 // ScoreConfig.soc_violation_penalty (score_config.py:26-30)
 __device__ __forceinline__ double soc_violation_penalty(double missing) {
-  return -500.0 / (1.0 + exp(-16.48461585 * (missing - 0.29229767))) + 1.0;
+  return -500.0 * rcp_newton(1.0 + exp(-16.48461585 * (missing - 0.29229767))) + 1.0;  // (<= 2 ulp of the quotient)
 }
 
 // ScoreConfig.overloading_penalty (score_config.py:33-41)
@@ -247,15 +274,6 @@ __device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
   return o;
 }
 
-// 1 / x for the auxiliary slots' one division: hardware reciprocal seed (v_rcp_f64, ~26 good bits) + two Newton steps = full
-// float64 accuracy (<= 1 ulp) in five instructions, against ~14 of the IEEE division sequence with its special-case handling.
-__device__ __forceinline__ double rcp_newton(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-
 // Per-EV slots of EV c.  soc / hours_left come from live state; the five auxiliary slots from the TABLE row the step
 // advanced to (quirk Q10): there | target_soc * there | charging_left | hours_needed | laxity (observer_bl_pv.py:85-91), each
 // divided by the normaliser's constant when normalize_in_env (oracle_normalization.py:127-131).  They are computed per lane
@@ -280,7 +298,7 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   const double tgt_th = tgt * th;
   const double cl = tgt_th - tb.sor;
   const double hn = cl * d.hn_scale;
-  double lax = ((double)tb.tl * rcp_newton(hn + 0.001) - 1.0) * th;
+  double lax = ((double)tb.tl * rcp_newton1(hn + 0.001) - 1.0) * th;
   lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);  // np.clip(., 0, 5): keeps -0.0 (an absent EV) and NaN like numpy does
   st_obs_at(a, o4, (float)tb.there);
   if (d.normalize) {
@@ -774,6 +792,19 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
 // For G == 64 a wavefront is one env: the env index, its time row and everything derived from them are made
 // wave-uniform (readfirstlane), which moves row addressing and the table-row loads to the scalar unit.
 // ---------------------------------------------------------------------------------------------------------
+// The leading arguments of fleet_step_kernel as the kernel-argument segment lays them out (natural alignment, declaration
+// order): where the argument block `d_arg` starts in the segment (`late_args`).
+struct StepKernargPrefix {
+  const Hot* p_hot;
+  const SegRec* p_run;
+  const double* p_soh;
+  const void* p_actions;
+  int p_E, p_N;
+  EnvRec* p_env;
+  FleetDev d_arg;
+};
+static_assert(offsetof(StepKernargPrefix, d_arg) == 48 && alignof(FleetDev) == 8, "twelve preloaded dwords, then the argument block");
+
 template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
 __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
@@ -799,7 +830,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   auto late_args = [&]() -> const FleetDev& {
     if constexpr (!MULTI && !WIDE) {
       typedef const __attribute__((address_space(4))) char* karg_ptr;
-      karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + 48;  // p_hot .. p_env: 4 x 8 + 2 x 4 + 8 bytes
+      karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StepKernargPrefix, d_arg);
       asm volatile("" : "+s"(kp));
       return *(const FleetDev*)(const __attribute__((address_space(4))) FleetDev*)kp;
     } else {
@@ -1083,12 +1114,12 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const double pen_raw = d.penalty_oc * (x * x);
       const double pen_oc = pos ? fmax(pen_raw, d.clip_oc) : pen_raw;
       rew += viol ? pen_oc : 0.0;
-      const double lim = need / d.eta_c;  // :114
+      const double lim = div_rcp(need, d.eta_c, d.inv_eta_c);  // need / eta_c, correctly rounded :114
       const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
       const double en = present ? en_p : 0.0;
       rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
       if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
-      soc = soc + (pos ? en * d.eta_c : en) / cap;  // :128 / :189
+      soc = soc + div_rcp(pos ? en * d.eta_c : en, cap, rcp_newton1(cap));  // soc + energy / cap, the quotient correctly rounded :128 / :189
       asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
       // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
@@ -1391,6 +1422,42 @@ __global__ void fleet_term_gather_kernel(const float* __restrict__ term, int obs
   }
 }
 
+// Self-test of div_rcp (fleet_selftest_division): operand pairs drawn the way the charge arithmetic forms them, the IEEE division
+// sequence beside the reciprocal form, bit for bit.  case 0: need / eta_c with the host's correctly rounded 1 / eta_c;
+// case 1: energy / cap with rcp_newton1(cap).  A few lanes in a thousand carry the edge values (+-0, a denormal-sized residue).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(unsigned long long h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+__global__ void fleet_selftest_division_kernel(unsigned long long n, unsigned long long seed, unsigned long long* __restrict__ bad) {
+  unsigned long long b0 = 0, b1 = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long h = mix64(seed + i * 4ull);
+    const double soc = -0.25 + 1.5 * u01(h), soh = 0.8 + 0.2 * u01(mix64(h)), init_cap = 10.0 + 90.0 * u01(mix64(h + 1));
+    const double eta = 0.5 + 0.5 * u01(mix64(h + 2)), tgt = (h & 1) ? 0.85 : 0.9;
+    const double a = 2.0 * u01(mix64(h + 3)) - 1.0, p_avail = 2.0 + 20.0 * u01(mix64(h + 4));
+    const double cap = soh * init_cap;
+    double need = (tgt - soc) * cap;
+    double en = p_avail * a * 0.25;
+    const unsigned sel = (unsigned)(h >> 40) % 1000u;
+    if (sel == 0) need = 0.0;
+    if (sel == 1) need = -0.0;
+    if (sel == 2) en = -0.0;
+    if (sel == 3) en = 7e-18 * cap;
+    const double inv_eta = 1.0 / eta;  // IEEE: correctly rounded, like the host's
+    const double q0 = need / eta, r0 = div_rcp(need, eta, inv_eta);
+    const double x1 = (a >= 0.0) ? en * eta : en;
+    const double q1 = x1 / cap, r1 = div_rcp(x1, cap, rcp_newton1(cap));
+    b0 += (__double_as_longlong(q0) != __double_as_longlong(r0));
+    b1 += (__double_as_longlong(q1) != __double_as_longlong(r1));
+  }
+  if (b0) atomicAdd(bad, b0);
+  if (b1) atomicAdd(bad + 1, b1);
+}
+
 int group_size(int N) {
   int G = 1;
   while (G < N && G < 64) G <<= 1;
@@ -1492,5 +1559,10 @@ hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t 
 hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s) {
   const size_t n = (size_t)d.E * d.N;
   hipLaunchKernelGGL(fleet_gather_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, field, out);
+  return hipGetLastError();
+}
+
+hipError_t fleet_launch_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* bad_dev, hipStream_t s) {
+  hipLaunchKernelGGL(fleet_selftest_division_kernel, dim3(2048), dim3(256), 0, s, n, seed, bad_dev);
   return hipGetLastError();
 }

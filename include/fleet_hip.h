@@ -343,6 +343,13 @@ int fleet_time_regions_read(fleet_handle h, float* region_ms);
 int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                          double* reward, uint8_t* done, float* per_launch_ms);
 
+/* ---- self-test --------------------------------------------------------------------------------------- */
+/* The charge arithmetic (EvCharger.charge, ev_charger.py:114,128,189) divides by eta_c and by the battery capacity; the kernels
+ * form both quotients from a reciprocal with a residual correction instead of the IEEE division sequence.  This entry runs both
+ * forms on `n_pairs` pseudo-random operand pairs of the charge arithmetic's ranges on the device and returns how many quotients
+ * differ in any bit: mismatches[0] for `need / eta_c`, mismatches[1] for `energy / cap` (expected: 0 and 0). */
+int fleet_selftest_division(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,16 @@ CONFIGS = {
     "ut3_both_norm_rainflow_spot21_feedin": (dict(use_case="ut", building_name="load_ut.csv", include_building=True, include_pv=True,
                                                   normalize_in_env=True, calculate_degradation=True, deg_emp=False, episode_length=24,
                                                   price_name="spot_2021_new.csv", tariff_name="fixed_feed_in.csv"), 3, 2, 2, "wide"),
+    # all four `ignore_*` switches of adjust_score_config (fleet_environment.py:1070-1078) at once: price reward, overloading,
+    # invalid-action and overcharging penalties zeroed; small grid connection and hard charging, so that every ignored term
+    # would have fired (same fleet as custom3_both_overload)
+    "custom3_both_overload_ignoreall": (dict(use_case="custom", building_name="load_lmd.csv", include_building=True,
+                                             include_pv=True, calculate_degradation=True, deg_emp=False, episode_length=24,
+                                             custom_ev_charger_power_in_kw=22, custom_ev_battery_size_in_kwh=40,
+                                             custom_grid_connection_in_kw=200, init_battery_cap=40, obc_max_power=11,
+                                             max_batt_cap_in_all_use_cases=60, ignore_price_reward=True,
+                                             ignore_overloading_penalty=True, ignore_invalid_penalty=True,
+                                             ignore_overcharging_penalty=True), 3, 2, 2, "full"),
 }
 
 
@@ -291,6 +301,9 @@ RT_CONFIGS = {
     # fleet_environment.py:994-1022).  Only the load+pv observer runs on it (the others look the window end up by exact date).
     # n_evs = 0: the shipped single-EV file; the first episode of env 0 starts on row 0 and walks the irregular rows.
     # the reference's DataLogger in real_time mode: a row for EVERY table row of the skipping loop (fleet_environment.py:677-690)
+    # real_time at the headline geometry: 50 EVs per env (1.6 s of reference time per table row), one env over an episode boundary
+    "ct50_both_rainflow": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
+                                calculate_degradation=True, deg_emp=False, episode_length=48, real_time=True), 50, 1, 2),
     "ct3_both_rainflow_log": (dict(use_case="ct", building_name="load_ct.csv", include_building=True, include_pv=True,
                                    calculate_degradation=True, deg_emp=False, episode_length=24, real_time=True, log_data=True), 3, 2, 2),
     "lmd1_both_irregular": (dict(use_case="lmd", schedule_name="test_lmd.csv", building_name="load_lmd.csv", include_building=True,

@@ -317,3 +317,14 @@ def test_rccl_gather_of_episode_stats_through_the_c_abi():
     assert (got[0, 1] == g.ep_steps).all()
     assert lib.fleet_rccl_comm_destroy(comm) == _capi.OK
     b.close()
+
+
+def test_division_by_reciprocal_is_bit_exact():
+    """The charge arithmetic's two divisions (ev_charger.py:114 `need / eta_c`, :128 / :189 `energy / cap`) are formed from a
+    reciprocal with a residual correction (fleet_kernels.hip div_rcp).  2^30 pseudo-random operand pairs of the charge
+    arithmetic's ranges -- incl. +-0 and a 7e-18-sized residue -- against the IEEE division sequence on the device: not one
+    quotient may differ in any bit."""
+    lib = _capi.load()
+    bad = (C.c_uint64 * 2)()
+    assert lib.fleet_selftest_division(0, 1 << 30, 12345, bad) == 0
+    assert (bad[0], bad[1]) == (0, 0), f"quotients that differ from the IEEE division: need/eta {bad[0]}, energy/cap {bad[1]}"

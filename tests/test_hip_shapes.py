@@ -105,6 +105,13 @@ def test_headline_shape_slice():
     _compare("ct", 50, 96, "rainflow", False, steps=220)
 
 
+def test_baseline_config1_at_its_nominal_size():
+    """BASELINE.json configs[1] as it is written: 256 envs x 5 EVs, last-mile delivery, price-only observations, linear
+    degradation, 48 h episodes with auto-reset (`bench.py --config c2`), against the oracle over two episodes and into the third
+    (the golden trace of this family, trace_lmd5_price_linear, pins 3 envs against the reference itself)."""
+    _compare("lmd", 5, 256, "linear", False, steps=400, building=False, pv=False, episode_length=48, seed=5)
+
+
 def test_long_soak_many_episodes():
     """1000 steps (ten 24 h episodes per env) at the headline geometry: accumulated degradation bookkeeping
     (rainflow_length / fd_cyc / l carried across episodes, quirk Q6) must stay in lock-step with the oracle."""

@@ -114,3 +114,94 @@ def test_structural_invariants():
         np.testing.assert_array_equal(t[:, 0], 2.0 * cyc[:, 0])
         np.testing.assert_array_equal(t[:, 1], -2.0 * cyc[:, 1] + 3.0)
         np.testing.assert_array_equal(t[:, 2:], cyc[:, 2:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# A second, independently written counting rule: the FOUR-point method (range-pair form; Amzallag et al. 1994,
+# the form most fatigue codes use).  Four successive reversals S1..S4: when the inner range |S3 - S2| is not larger than both
+# outer ranges, (S2, S3) is a closed cycle and is deleted; what cannot be closed is the residue.  McInnes & Meehan (2008,
+# "Equivalence of four-point and three-point rainflow cycle counting algorithms") show that the three-point ASTM rule the
+# `rainflow` package implements yields the same closed cycles, and that its half cycles are the successive ranges of the
+# four-point residue.  Different program, different data flow (no "contains the starting point" case at all) -- same counts.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _four_point(points):
+    stack, full = [], []
+    for p in points:
+        stack.append(p)
+        while len(stack) >= 4:
+            s1, s2, s3, s4 = stack[-4:]
+            inner = abs(s3 - s2)
+            if inner <= abs(s2 - s1) and inner <= abs(s4 - s3):
+                full.append((inner, 0.5 * (s2 + s3)))
+                del stack[-3:-1]
+            else:
+                break
+    return full, stack  # closed cycles, residue
+
+
+def _histogram(cycles):
+    """{range: [sum of counts, count-weighted sum of means]}: two half cycles of one range are one full cycle of it."""
+    h = {}
+    for rng, mean, count in cycles:
+        e = h.setdefault(float(rng), [0.0, 0.0])
+        e[0] += count
+        e[1] += count * mean
+    return h
+
+
+def _assert_same_counts(series, what=""):
+    pts = _reversals(series)
+    full, residue = _four_point(pts)
+    four = [(r, m, 1.0) for r, m in full] + [(abs(b - a), 0.5 * (a + b), 0.5) for a, b in zip(residue[:-1], residue[1:])]
+    three = [(r, m, c) for r, m, c, _e in rainflow(series)]
+    h4, h3 = _histogram(four), _histogram(three)
+    assert sorted(h4) == sorted(h3), f"ranges differ {what}"
+    for r in h3:
+        assert h4[r][0] == h3[r][0], f"count of range {r} {what}: four-point {h4[r][0]}, three-point {h3[r][0]}"
+        assert abs(h4[r][1] - h3[r][1]) <= 1e-12 * max(1.0, abs(h3[r][1])), f"means of range {r} {what}"
+    # the damage-relevant totals the SEI model consumes (rainflow_sei_degradation.py:140,170-174): number of cycles' worth,
+    # sum of ranges * counts
+    assert sum(c for _r, _m, c in four) == sum(c for _r, _m, c in three)
+
+
+def test_four_point_method_gives_the_same_counts_on_synthetic_series():
+    rng = np.random.default_rng(23)
+    for n in (4, 5, 9, 33, 96, 193, 500, 2000):
+        for _ in range(20):
+            _assert_same_counts(np.cumsum(rng.integers(-40, 41, size=n)) / 1024.0, f"(random walk, n={n})")
+            _assert_same_counts(np.clip(np.cumsum(rng.integers(-300, 301, size=n)) / 1024.0, 0.0, 1.0), f"(saturating, n={n})")
+    _assert_same_counts(np.array([(-1) ** k * k for k in range(40)]) / 64.0, "(growing zigzag)")
+    _assert_same_counts(np.array([(-1) ** k * (40 - k) for k in range(40)]) / 64.0, "(shrinking zigzag)")
+    _assert_same_counts([-2, 1, -3, 5, -1, 3, -4, 4, -2], "(ASTM E1049-85 example)")
+
+
+def test_three_implementations_agree_on_the_soc_series_of_every_rainflow_golden():
+    """The stand-in for rainflow==3.2.0 (through which every rainflow-mode golden was produced), the C oracle's own rainflow and
+    the four-point method on the logged SOC series (LogDataDeg.soc_log: the reset sample + one per step) of every EV of every
+    episode of every rainflow-mode golden trace."""
+    import os
+    import sys
+
+    from golden_util import TRACE_NAMES, load_trace
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "stubs"))
+    import rainflow as standin  # noqa: E402  (oracle/stubs/rainflow: test infrastructure)
+
+    seen = 0
+    for name in TRACE_NAMES:
+        g = load_trace(name)
+        if g.rc.deg_mode != 2:
+            continue
+        for e in range(g.E):
+            for ep in range(g.episodes):
+                for c in range(g.N):
+                    first = g.reset_soc[e, ep, c]
+                    first = g.rc.def_soc if first == 0 else first  # fleet_environment.py:395-399
+                    s = np.concatenate([[first], g.soc_deg[e, ep * g.ep_steps:(ep + 1) * g.ep_steps, c]])
+                    what = f"({name}, env {e}, episode {ep}, EV {c})"
+                    _assert_same_counts(s, what)
+                    a = [(r, m, cnt, i1) for r, m, cnt, _i0, i1 in standin.extract_cycles(list(s))]
+                    b = [tuple(row) for row in rainflow(s)]
+                    assert a == b, f"stand-in and C oracle differ {what}"
+                    seen += 1
+    assert seen >= 100
