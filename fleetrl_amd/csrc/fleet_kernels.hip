@@ -650,59 +650,87 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
 // ---------------------------------------------------------------------------------------------------------
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
+// FleetEnv.reset in two parts -- what each EV of the env does for itself, and what is done once per env -- so that both lane
+// mappings can use them (a group of G lanes per env: reset_env below; one EV per lane with the envs packed densely: the flat step
+// kernel, where the env's part is run by another thread than its EVs').
+// The EV's part (fleet_environment.py:345-399): state of health, SOC / hours_left from the start row, laxity fix-up, first SOC
+// sample, the carried schedule record, the observation slots.  `log_obs_row` / `log_ev_soh`: the data log's row reset() writes.
+__device__ __forceinline__ void reset_ev(const FleetDev& d, int e, int c, int start, float* __restrict__ obs_row,
+                                         float* __restrict__ log_obs_row, double* __restrict__ log_ev) {
+  const int N = d.N;
+  const FleetCold* cd = d.cold;
+  const int next = start + 1 > d.T - 1 ? d.T - 1 : start + 1;
+  const EvIx ix = {(size_t)e * N, (unsigned)c};
+  const size_t i = ix.flat();
+  const SegRec s0 = d.seg[(size_t)start * N + c];
+  d.run[i] = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
+  const RowRec tb = seg_row(s0, start, d.dt);
+  const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
+  const double soh = 1.0 * cd->init_soh;
+  const double cap = soh * d.init_cap;
+  double soc = tb.sor;
+  const float hl = tb.tl;
+  const double tgt = t090 ? 0.9 : d.target_soc;
+  const double time_needed = (tgt - soc) * cap / d.p_avail;              // :384
+  if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
+    soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
+  const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
+  d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
+  d.soh[i] = soh;
+  if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
+    RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
+    RfHdr hd = *hp;  // rainflow_length survives
+    hd.mean_sum = 0.0;
+    hd.csum = 0.0;
+    hd.nc = 0;
+    hd.s1 = 0.0;
+    hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
+    *hp = hd;
+  }
+  if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
+  if (log_obs_row) {
+    write_obs_ev(d, log_obs_row, c, soc, hl, tgt, tb);
+    double* lev = log_ev + c;
+    lev[0] = 0.0;
+    lev[N] = 0.0;
+    lev[2 * N] = 0.0;
+    lev[3 * N] = soh;
+  }
+}
+// Start row, finish row and sample count of the env's next episode (time pickers, :351-355) -- every lane of the env computes
+// them for itself (registers, no exchange).
+__device__ __forceinline__ int reset_times(const FleetDev& d, int e, EnvHead& r) {
+  const int start = choose_start(d.cold, d.E, e, r.episodes);
+  r.t = start;
+  r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
+  r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
+  return start;
+}
+// The env's part: its record (episode counters zeroed :402-404, the head with the row flags the episode's first step needs).
+__device__ __forceinline__ void reset_head(const FleetDev& d, int e, const EnvHead& r, int start) {
+  EnvRec* er = d.env + e;
+  EnvHead hd = r;
+  hd.nsamp = HEAD_PACK(r.nsamp, d.tab_phys[start].flags_next);
+  er->h = hd;
+  er->ep_return = 0.0;
+  er->ep_len = 0;
+  er->penalty_record = 0.0;
+  er->start_done = start;  // bit 31 (episode.done) cleared
+  // (an episode whose finish row lies beyond the table is legal until a step leaves the table: FLEET_DEVERR_TABLE_END is raised
+  // there, like the KeyError of the reference's `db.loc[...]`)
+}
+
 // `lp`: the env's data-log cursor (rows written so far; only used when the log is on), advanced by the row reset() writes.
 template <int G, bool LOG>
 __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
   const bool log_on = LOG && (d.log_pos != nullptr);
   const int N = d.N;
-  const FleetCold* cd = d.cold;
-  const int start = choose_start(cd, d.E, e, r.episodes);
-  r.t = start;
-  r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
-  r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
+  const int start = reset_times(d, e, r);
   // data log: the row reset() writes -- time, observation and SoH, zeros for everything else (:420-432)
   const size_t lrow = log_on ? (size_t)(lp % d.log_cap) * d.E + e : 0;
   float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
-  const int next = start + 1 > d.T - 1 ? d.T - 1 : start + 1;
-  for (int c = g; c < N; c += G) {
-    const EvIx ix = {(size_t)e * N, (unsigned)c};
-    const size_t i = ix.flat();
-    const SegRec s0 = d.seg[(size_t)start * N + c];
-    const SegRec s1 = d.seg[(size_t)next * N + c];  // the record the first step of the episode advances to
-    const RowRec tb = seg_row(s0, start, d.dt);
-    const bool t090 = HOT_T090(d.hot[i].bits);  // target_soc survives reset (quirk Q7)
-    const double soh = 1.0 * cd->init_soh;
-    const double cap = soh * d.init_cap;
-    double soc = tb.sor;
-    const float hl = tb.tl;
-    const double tgt = t090 ? 0.9 : d.target_soc;
-    const double time_needed = (tgt - soc) * cap / d.p_avail;              // :384
-    if ((hl > 0.0f) && (cd->min_laxity * time_needed > (double)hl))        // :388
-      soc = tgt - (time_needed * d.p_avail / cap) / cd->min_laxity;        // :389-390
-    const double soc_deg = (soc == 0.0) ? cd->def_soc : soc;               // :395-399
-    d.hot[i] = hot_encode(d, ix, soc, soc_deg, hl, 1, 0, tb.there, t090, false);  // rainflow: the first sample is the first reversal point
-    d.run[i] = s1;
-    d.soh[i] = soh;
-    if (d.deg_mode == FLEET_DEG_RAINFLOW) {  // LogDataDeg restarts; the SEI bookkeeping does NOT (quirk Q6)
-      RfHdr* hp = reinterpret_cast<RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride);
-      RfHdr hd = *hp;  // rainflow_length survives
-      hd.mean_sum = 0.0;
-      hd.csum = 0.0;
-      hd.nc = 0;
-      hd.s1 = 0.0;
-      hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
-      *hp = hd;
-    }
-    if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
-    if (log_on) {
-      write_obs_ev(d, log_obs_row, c, soc, hl, tgt, tb);
-      double* lev = d.log_ev + lrow * 4 * N + c;
-      lev[0] = 0.0;
-      lev[N] = 0.0;
-      lev[2 * N] = 0.0;
-      lev[3 * N] = soh;
-    }
-  }
+  double* const log_ev = log_on ? d.log_ev + lrow * 4 * N : nullptr;
+  for (int c = g; c < N; c += G) reset_ev(d, e, c, start, obs_row, log_obs_row, log_ev);
   if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
   if (log_on) {
     write_obs_tail<G>(d, log_obs_row, start, g);
@@ -713,18 +741,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     }
     lp += 1;
   }
-  if (leader) {
-    EnvRec* er = d.env + e;
-    EnvHead hd = r;
-    hd.nsamp = HEAD_PACK(r.nsamp, d.tab_phys[start].flags_next);  // the row flags the episode's first step needs
-    er->h = hd;
-    er->ep_return = 0.0;
-    er->ep_len = 0;
-    er->penalty_record = 0.0;
-    er->start_done = start;  // bit 31 (episode.done) cleared
-    // (an episode whose finish row lies beyond the table is legal until a step leaves the table: FLEET_DEVERR_TABLE_END is raised
-    // there, like the KeyError of the reference's `db.loc[...]`)
-  }
+  if (leader) reset_head(d, e, r, start);
 }
 
 template <int G>
@@ -782,6 +799,94 @@ __device__ __forceinline__ void ev_finish(const FleetDev& d, const EvIx& i, int 
     if (crosses) st_rec16(ev_at(d.run, i), nr);  // the next launch advances into another segment of the EV's schedule
     if (DEG == FLEET_DEG_LINEAR && deg_row) *ev_at(d.soh, i) = soh;  // battery_cap = soh * init_cap is recomputed on use (:673)
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One EV's share of a step: EvCharger.charge (ev_charger.py:89-222) and the arrival / departure state machine
+// (fleet_environment.py:528-623), without the money terms (they wait for the time row's physics record).  Shared by every
+// step kernel.  `hb` = the EV's hot record, `old_deg` = its last logged SOC sample, `tb1` = the schedule columns of the row the
+// step advances to, `soh0` = its state of health, `a` = its action.
+// ---------------------------------------------------------------------------------------------------------
+struct EvPhys {
+  double soc, soc_deg;  // episode.soc / episode.soc_deg after the step
+  double en;            // charged (> 0) / discharged (< 0) energy; 0 for an absent EV (:114 / :174)
+  double rew;           // penalties and rewards of the EV except the price terms
+  double penrec, miss;  // episode.penalty_record / cum_soc_missing contributions (:544-584)
+  double a_th;          // action * there (fleet_environment.py:491)
+  float hl;             // episode.hours_left
+  bool pos, t090;       // action >= 0; sticky "target_soc = 0.9" (quirk Q7)
+  bool event;           // MULTI: something the reference counts into episode.events (real_time)
+};
+template <bool MULTI>
+__device__ __forceinline__ EvPhys ev_physics(const FleetDev& d, const Hot& hb, double old_deg, const RowRec& tb1, double soh0, double a,
+                                             double dt_step, bool lunch) {
+  EvPhys o;
+  double rew = 0.0, penrec = 0.0, miss_sum = 0.0;
+  bool ev_lane = false;
+  const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
+  double soc = HOT_SOC(hb);
+  float hl = hb.hl;
+  const double cap = soh0 * d.init_cap;
+  bool t090 = HOT_T090(hb.bits);
+  const double tgt = t090 ? 0.9 : d.target_soc;
+  const bool present = (th == 1u);
+
+  // ---- EvCharger.charge (ev_charger.py:89-222) -----------------------------------------------------------------
+  // Both action signs in ONE straight-line flow: every quantity of both branches is computed unconditionally and
+  // merged with selects / min / max, so a wavefront whose lanes hold both signs (the normal case) does not walk two
+  // masked branches, and there is no exec-mask bookkeeping on the hot path.
+  const bool pos = (a >= 0.0);
+  const double dem = d.p_avail * a * dt_step;   // demanded (dis)charge energy :101 / :162
+  const double need = (tgt - soc) * cap;     // ev_total_energy_demand :100
+  const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
+  // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
+  // :165-167 (needs presence, not clipped)
+  const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
+  const double x = pos ? (dem - need) : (left - dem);
+  const double pen_raw = d.penalty_oc * (x * x);
+  const double pen_oc = pos ? fmax(pen_raw, d.clip_oc) : pen_raw;
+  rew += viol ? pen_oc : 0.0;
+  const double lim = div_rcp(need, d.eta_c, d.inv_eta_c);  // need / eta_c, correctly rounded :114
+  const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
+  const double en = present ? en_p : 0.0;
+  rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
+  if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
+  soc = soc + div_rcp(pos ? en * d.eta_c : en, cap, rcp_newton1(cap));  // soc + energy / cap, the quotient correctly rounded :128 / :189
+  o.a_th = a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
+
+  // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
+  const float ntl = tb1.tl;
+  // departure :532, arrival :603, low state of health :615 are events too
+  if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (soh0 <= 0.9);
+  if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
+    const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
+    const double missing = target - soc;
+    if (missing > d.eps) {
+      const double pen = soc_violation_penalty(missing);
+      rew += pen;
+      penrec += pen;  // episode.penalty_record (:549,566,584)
+      miss_sum += missing;  // cum_soc_missing (:544,561,579), only reported through the data log
+    } else {
+      rew += d.fully_charged_reward;
+    }
+  }
+  {
+    const bool staying = (ntl != 0.0f) && (hl != 0.0f);  // still charging :593-594; otherwise no car in the next
+    hl = staying ? (float)((double)hl - dt_step) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
+    soc = staying ? soc : tb1.sor;                       // `else: raise` is unreachable)
+  }
+  if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
+  o.soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
+  o.soc = soc;
+  o.hl = hl;
+  o.en = en;
+  o.rew = rew;
+  o.penrec = penrec;
+  o.miss = miss_sum;
+  o.pos = pos;
+  o.t090 = t090;
+  o.event = ev_lane;
+  return o;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1090,61 +1195,17 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       const EvIx it2 = {(size_t)t2 * N, (unsigned)c};
       if (crosses) nr = *ev_at(d.seg, it2);
       const RowRec tb1 = seg_row(rr, t1, d.dt);
-      const uint32_t th = HOT_THERE(hb.bits);  // There at the current time row, carried from the previous step / reset
-      double soc = HOT_SOC(hb);
-      float hl = hb.hl;
-      const double cap = soh0 * d.init_cap;
-      bool t090 = HOT_T090(hb.bits);
-      const double tgt = t090 ? 0.9 : d.target_soc;
-      const bool present = (th == 1u);
-
       FLEET_STAMP(2);
-      // ---- EvCharger.charge (ev_charger.py:89-222) -----------------------------------------------------------------
-      // Both action signs in ONE straight-line flow: every quantity of both branches is computed unconditionally and
-      // merged with selects / min / max, so a wavefront whose lanes hold both signs (the normal case) does not walk two
-      // masked branches, and there is no exec-mask bookkeeping on the hot path.
-      const bool pos = (a >= 0.0);
-      const double dem = d.p_avail * a * dt_step;   // demanded (dis)charge energy :101 / :162
-      const double need = (tgt - soc) * cap;     // ev_total_energy_demand :100
-      const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
-      // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
-      // :165-167 (needs presence, not clipped)
-      const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
-      const double x = pos ? (dem - need) : (left - dem);
-      const double pen_raw = d.penalty_oc * (x * x);
-      const double pen_oc = pos ? fmax(pen_raw, d.clip_oc) : pen_raw;
-      rew += viol ? pen_oc : 0.0;
-      const double lim = div_rcp(need, d.eta_c, d.inv_eta_c);  // need / eta_c, correctly rounded :114
-      const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
-      const double en = present ? en_p : 0.0;
-      rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
-      if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
-      soc = soc + div_rcp(pos ? en * d.eta_c : en, cap, rcp_newton1(cap));  // soc + energy / cap, the quotient correctly rounded :128 / :189
-      asum += a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
-
-      // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
-      const float ntl = tb1.tl;
-      // departure :532, arrival :603, low state of health :615 are events too
-      if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (soh0 <= 0.9);
-      if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
-        const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
-        const double missing = target - soc;
-        if (missing > d.eps) {
-          const double pen = soc_violation_penalty(missing);
-          rew += pen;
-          penrec += pen;  // episode.penalty_record (:549,566,584)
-          miss_sum += missing;  // cum_soc_missing (:544,561,579), only reported through the data log
-        } else {
-          rew += d.fully_charged_reward;
-        }
-      }
-      {
-        const bool staying = (ntl != 0.0f) && (hl != 0.0f);  // still charging :593-594; otherwise no car in the next
-        hl = staying ? (float)((double)hl - dt_step) : ntl;     // step :597-599 or a new arrival :602-606 (the reference's
-        soc = staying ? soc : tb1.sor;                       // `else: raise` is unreachable)
-      }
-      if (soh0 <= 0.9) t090 = true;  // :613-614 sticky target (quirk Q7)
-      const double soc_deg = (hl != 0.0f) ? soc : old_deg;  // :621-623
+      const EvPhys ph_ev = ev_physics<MULTI>(d, hb, old_deg, tb1, soh0, a, dt_step, lunch);
+      double soc = ph_ev.soc;
+      float hl = ph_ev.hl;
+      const bool t090 = ph_ev.t090, pos = ph_ev.pos;
+      const double en = ph_ev.en, soc_deg = ph_ev.soc_deg;
+      rew += ph_ev.rew;
+      penrec += ph_ev.penrec;
+      miss_sum += ph_ev.miss;
+      asum += ph_ev.a_th;
+      if (MULTI) ev_lane = ev_lane || ph_ev.event;
       // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
       // here and consumed after the observation stores and the money terms
       int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
@@ -1294,8 +1355,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
   {  // ---- after the steps: again through the freshly read block ----
   const FleetDev& d = late_args();
-  // (only where a single-step launch can follow on the same handle: with more EVs than lanes every kernel reads the table)
-  if (!kEarly && !WIDE && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
+  // (only where a single-step launch that reads them can follow on the same handle: with more EVs than lanes the grouped kernels
+  // read the table -- unless the handle's single steps run the flat kernel, which carries the records like the narrow one)
+  if (!kEarly && (!WIDE || d.flat_step) && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
     const int rn = r.t + 1 > d.T - 1 ? d.T - 1 : r.t + 1;
     for (int c = g; c < N; c += G) d.run[(size_t)e * N + c] = d.seg[(size_t)rn * N + c];
   }
@@ -1324,6 +1386,223 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   }  // late_args scope
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The step with the envs packed densely into the workgroup: ONE EV PER LANE for any number of EVs per env, lane l of a workgroup
+// that holds `epw` envs owns EV (l mod N) of env (l div N) -- 5 envs of 50 EVs in 256 lanes (250 busy), 5 envs of 200 EVs in 1024
+// (1000 busy) -- instead of a power-of-two group of lanes per env (50 EVs: 64 lanes, 78 % busy; 200 EVs: 64 lanes walking four
+// EVs each, one after the other).  An env's lanes may straddle wavefronts, so the four per-env sums go through the LDS: every
+// lane stores its four terms (one plane per quantity), the workgroup meets at one barrier, and 16 lanes per env -- four per
+// quantity -- add the env's terms up; the last of the sixteen is the env's LEADER and does what is done once per env: overload
+// penalty, episode bookkeeping, reward / done, the head of the env's record.  The leader is not one of the env's EV lanes in
+// general: it reads the env's record and the time row's physics scalars for itself when the launch starts.
+// One step per launch, no data log, no real_time (those run the grouped kernel's multi-step form).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quad_sum(double v) {  // sum over the lane's aligned quad, valid in all four lanes
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
+  lo = __double2loint(v), hi = __double2hiint(v);
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
+  return v;
+}
+template <int SHR>
+__device__ __forceinline__ double row_from(double v) {  // the value of the lane SHR places down the 16-lane row (row_shr:SHR)
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + SHR, 0xF, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + SHR, 0xF, 0xF, true));
+}
+
+template <int DEG, bool A64>
+__global__ __launch_bounds__(1024) void fleet_step_flat_kernel(
+    // (the same leading arguments as fleet_step_kernel: preloaded into scalar registers at wave launch)
+    const Hot* p_hot, const SegRec* p_run, const double* p_soh, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* p_env,
+    FleetDev d, int epw, uint32_t magic, float* __restrict__ obs, double* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ terminal_obs) {
+  extern __shared__ double flat_lds[];  // [4][blockDim.x]: cashflow, reward, sum(action * there), penalty record terms
+  const int N = p_N, E_ = p_E;
+  const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+  // ---- the lane as an EV ----
+  const int el = (int)(((uint32_t)tid * magic) >> 20);  // tid / N (exact for tid < 1024, N < 1024: fleet_launch_step checks)
+  const int c = tid - el * N;
+  const int e_raw = (int)blockIdx.x * epw + el;
+  const bool ev_ok = (el < epw) && (e_raw < E_);  // surplus lanes run the arithmetic on the last env's EV and store nothing
+  const int e = e_raw < E_ ? e_raw : E_ - 1;
+  const EvIx i = {(size_t)e * N, (unsigned)c};
+  const size_t f0 = i.flat();
+  const Hot hb = p_hot[f0];
+  const double soh0 = p_soh[f0];
+  double a64_pre = 0.0;
+  float a32_pre = 0.0f;
+  if (A64) a64_pre = ((const double*)p_actions)[f0];
+  else a32_pre = ((const float*)p_actions)[f0];
+  const SegRec rr = p_run[f0];
+  EnvHead r = p_env[e].h;
+  // ---- the lane as an env's leader (the last of the env's sixteen reducer lanes) ----
+  const int jl = tid >> 4;
+  const int e_led = (int)blockIdx.x * epw + jl;
+  const bool leads = ((tid & 15) == 15) && (jl < epw) && (e_led < E_);
+  EnvHead rl = {0, 0, 0, 0};
+  double ep_return = 0.0, penalty_record = 0.0, l_load = 0.0, l_pv = 0.0;
+  int ep_len = 0;
+  uint32_t l_flags_after = 0;
+  if (leads) {
+    const EnvRec* er = p_env + e_led;
+    rl = er->h;
+    ep_return = er->ep_return;
+    penalty_record = er->penalty_record;
+    ep_len = er->ep_len;
+  }
+
+  const uint32_t head_flags = HEAD_FLAGS(r.nsamp);  // FLEET_TFLAG_* of row t + 1, left by the previous launch
+  r.nsamp = HEAD_NSAMP(r.nsamp);
+  uint32_t err = 0;
+  const int t = r.t;
+  int t1 = t + 1;  // :508
+  if (t1 > d.T - 1) { t1 = d.T - 1; err |= FLEET_DEVERR_TABLE_END; }
+  const int t2 = t1 + 1 > d.T - 1 ? d.T - 1 : t1 + 1;  // the row the NEXT step advances to
+  const bool is_done = (t + 1 == r.t_end);  // :627-628
+  const bool resets = is_done && d.auto_reset;
+  float* const obs_row = obs + (size_t)e * d.obs_dim;
+  float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
+  float* const step_row = resets ? term_row : obs_row;  // with vec-env auto-reset the terminal observation is reported aside
+  const bool write_step_obs = ev_ok && (step_row != nullptr);
+  // time-row loads, consumed late: the physics record (money terms) and the lane's words of the observation tail
+  const PhysHot ph = *reinterpret_cast<const PhysHot*>(d.tab_phys + t);
+  const int tail_total = d.tail_a_len + d.tail_b_len;
+  const float tail_first = (c < tail_total) ? d.tab_tail[(size_t)t1 * d.tail_stride + c] : 0.0f;
+  if (leads) {
+    const int tl = rl.t;
+    const int tl1 = tl + 1 > d.T - 1 ? d.T - 1 : tl + 1;
+    const PhysHot* pl = reinterpret_cast<const PhysHot*>(d.tab_phys + tl);
+    l_load = pl->load;
+    l_pv = pl->pv;
+    l_flags_after = reinterpret_cast<const PhysHot*>(d.tab_phys + tl1)->flags_next;
+  }
+  const double dt_step = d.dt;
+  const bool lunch = d.is_caretaker && (head_flags & FLEET_TFLAG_LUNCH);
+  const bool deg_row = (DEG != FLEET_DEG_NONE) && (head_flags & FLEET_TFLAG_DEG);
+
+  // ---- the EV's step (as in fleet_step_kernel, one EV per lane) ----
+  const bool inplane = HOT_INPLANE(hb.bits);
+  double old_deg = hb.x;
+  if (inplane) old_deg = d.soc_deg[f0];
+  const double a = A64 ? a64_pre : (double)a32_pre;
+  const bool crosses = (t1 + 1 >= SEG_END(rr.se));
+  SegRec nr = rr;
+  if (crosses) nr = d.seg[(size_t)t2 * N + c];
+  const RowRec tb1 = seg_row(rr, t1, d.dt);
+  const EvPhys pe = ev_physics<false>(d, hb, old_deg, tb1, soh0, a, dt_step, lunch);
+  int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
+  RfReq rq;
+  rq.push = false;
+  rq.win = false;
+  if (DEG == FLEET_DEG_RAINFLOW && ev_ok) rf_begin(d, i, old_deg, pe.soc_deg, tail, sgn, rq);
+  const double tgt_obs = pe.t090 ? 0.9 : d.target_soc;  // the target the observer sees: after this step's sticky update
+  if (write_step_obs) write_obs_ev(d, step_row, c, pe.soc, pe.hl, tgt_obs, tb1);
+  double cash, rew = pe.rew;
+  {
+    const double grid_e = fmax(pe.en - ph.pv_share, 0.0);  // :142 (charging only)
+    cash = pe.pos ? -(grid_e * ph.k_cost) : pe.en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
+    rew += pe.pos ? ph.k_charge * grid_e : ph.k_discharge * pe.en;  // :154-156 / :204-206
+  }
+  double sei_sample = 0.0, sei_soh = 0.0;
+  int sei_tail = 0;
+  RfTop sei_top = {0.0, 0.0};
+  bool sei_have_top = false;
+  RfAccHead acc_c = {0.0, 0, 0};
+  RfTop top_c = {0.0, 0.0};
+  ev_finish<DEG, false>(d, i, c, N, ev_ok, deg_row, dt_step, rq, tail, sgn, pe.soc, pe.soc_deg, old_deg, pe.hl, tb1.there, pe.t090, inplane,
+                        crosses, nr, soh0, a, pe.en, false, 0, hb, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c, top_c,
+                        false);
+  // the env-level observation blocks: lane c copies tail word c, c + N, ... of the row the step advanced to
+  if (write_step_obs) {
+    const int na = d.tail_a_len;
+    const unsigned base_a = 2u * (unsigned)N, base_b = 7u * (unsigned)N;  // block B: 2N + na + 5N + (j - na) = 7N + j
+    if (c < tail_total) st_obs(step_row + ((c < na ? base_a : base_b) + (unsigned)c), tail_first);
+    for (int j = c + N; j < tail_total; j += N) step_row[(j < na ? base_a : base_b) + (unsigned)j] = d.tab_tail[(size_t)t1 * d.tail_stride + j];
+  }
+  if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
+
+  // ---- the four per-env terms of this EV go to the LDS (a lane that owns no EV contributes nothing) ----
+  flat_lds[tid] = ev_ok ? cash : 0.0;
+  flat_lds[nthr + tid] = ev_ok ? rew : 0.0;
+  flat_lds[2 * nthr + tid] = ev_ok ? pe.a_th : 0.0;
+  flat_lds[3 * nthr + tid] = ev_ok ? pe.penrec : 0.0;
+
+  // ---- daily SEI evaluation (:666-671), the EV's own ----
+  if (DEG == FLEET_DEG_RAINFLOW && deg_row && ev_ok) {
+    const double deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step, nullptr);
+    d.soh[f0] = sei_soh - deg;
+  }
+  // ---- episode end: the EV's part of the auto-reset ----
+  if (resets && ev_ok) {
+    r.episodes += 1;
+    const int start = reset_times(*d.self, e, r);
+    reset_ev(*d.self, e, c, start, obs_row, nullptr, nullptr);
+    const int na = d.tail_a_len;
+    const unsigned base_a = 2u * (unsigned)N, base_b = 7u * (unsigned)N;
+    for (int j = c; j < tail_total; j += N) obs_row[(j < na ? base_a : base_b) + (unsigned)j] = d.tab_tail[(size_t)start * d.tail_stride + j];
+  }
+  if (err && ev_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
+    atomicOr(&d.env[e].err, err);
+    atomicOr(d.self->err_any, err);
+  }
+
+  __syncthreads();
+  // ---- per-env sums: lane k of the env's sixteen adds every fourth term of quantity k / 4, the quad finishes it ----
+  if (jl < epw) {
+    const int q = (tid >> 2) & 3, k4 = tid & 3;
+    const double* src = flat_lds + q * nthr + jl * N;
+    double sum = 0.0;
+    for (int m = k4; m < N; m += 4) sum += src[m];
+    sum = quad_sum(sum);
+    // lanes 3, 7, 11, 15 of the row hold cashflow, reward, sum(action * there), penalty record: bring them to lane 15
+    const double s_cash = row_from<12>(sum), s_rew = row_from<8>(sum), s_asum = row_from<4>(sum), s_pen = sum;
+    if (leads) {
+      const int el_ = e_led;
+      const int tl = rl.t;
+      int tl1 = tl + 1;
+      if (tl1 > d.T - 1) tl1 = d.T - 1;
+      const bool l_done = (tl + 1 == rl.t_end);
+      double rew_e = s_rew;
+      penalty_record += s_pen;
+      // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
+      const double head_room = d.grid_connection - l_load - s_asum * d.evse_power + l_pv;
+      const double over = fabs(head_room < 0.0 ? head_room : 0.0);
+      if (over > 0.0) {
+        const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
+        rew_e += pen;
+        penalty_record += pen;
+      }
+      ep_return += rew_e;  // :637
+      ep_len += 1;
+      EnvRec* er = d.env + el_;
+      er->cashflow = s_cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
+      reward[el_] = rew_e;
+      done[el_] = l_done ? 1 : 0;
+      int nsamp = HEAD_NSAMP(rl.nsamp);
+      if (DEG != FLEET_DEG_NONE) nsamp += 1;
+      rl.t = tl1;
+      if (l_done) {
+        er->last_ep_return = ep_return;
+        er->last_ep_len = ep_len;
+        rl.episodes += 1;
+        if (d.auto_reset) {
+          const int start = reset_times(*d.self, el_, rl);
+          reset_head(*d.self, el_, rl, start);
+        } else {
+          er->start_done |= (int32_t)0x80000000u;  // episode.done
+        }
+      }
+      if (!(l_done && d.auto_reset)) {
+        rl.nsamp = HEAD_PACK(nsamp, l_flags_after);  // the head carries the row flags the next launch's state machine needs
+        er->h = rl;
+        er->ep_return = ep_return;
+        er->ep_len = ep_len;
+        er->penalty_record = penalty_record;
+      }
+    }
+  }
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)
@@ -1464,6 +1743,33 @@ int group_size(int N) {
   return G;
 }
 
+// Workgroup geometry of the flat step kernel for N EVs per env: W wavefronts holding epw = (64 W) div N whole envs.  The fullest
+// workgroup wins; among equally full ones the smallest (its barrier joins fewer wavefronts).
+struct FlatGeom {
+  int waves, epw;
+};
+FlatGeom flat_geom(int N) {
+  FlatGeom best = {0, 0};
+  double best_fill = 0.0;
+#ifdef FLEET_FLAT_W  // experiments only (tools/r05_build_variants.sh): a fixed workgroup size
+  for (int W = FLEET_FLAT_W; W <= FLEET_FLAT_W; ++W) {
+#else
+  for (int W = (N <= 64 ? 4 : (N + 63) / 64); W <= 16; W += (N <= 64 ? 4 : 1)) {
+#endif
+    const int epw = (64 * W) / N;
+    if (epw < 1) continue;
+    const double fill = (double)(epw * N) / (64.0 * W);
+    if (fill > best_fill + 1e-9) {
+      best_fill = fill;
+      best = {W, epw};
+    }
+  }
+  return best;
+}
+// One EV per lane pays where the grouped mapping leaves lanes idle or walks several EVs per lane: N > 64, or N between two
+// powers of two (profiles/r05_experiments/flat_*.log).  Small fleets (N <= 16) keep their power-of-two groups.
+bool flat_applies(int N) { return N > 16 && N < 1024 && (N > 64 || (N & (N - 1)) != 0); }
+
 template <int G, int DEG>
 hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
@@ -1473,6 +1779,19 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
+  if (single && d.flat_step && G >= 32) {
+    const FlatGeom fg = flat_geom(d.N);
+    const dim3 fgrid((d.E + fg.epw - 1) / fg.epw), fblock(64 * fg.waves);
+    const size_t lds = (size_t)4 * 64 * fg.waves * sizeof(double);
+    const uint32_t magic = (1u << 20) / (uint32_t)d.N + 1u;
+    if (f64 == FLEET_ACT_F64)
+      hipLaunchKernelGGL((fleet_step_flat_kernel<DEG, true>), fgrid, fblock, lds, s, FLEET_PRE_ARGS d, fg.epw, magic, obs, reward, done,
+                         terminal_obs);
+    else
+      hipLaunchKernelGGL((fleet_step_flat_kernel<DEG, false>), fgrid, fblock, lds, s, FLEET_PRE_ARGS d, fg.epw, magic, obs, reward, done,
+                         terminal_obs);
+    return hipGetLastError();
+  }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,
@@ -1529,6 +1848,14 @@ hipError_t launch_reset_g(const FleetDev& d, const uint8_t* mask, float* obs, hi
     case 32: return CALL(32);              \
     default: return CALL(64);              \
   }
+
+bool fleet_flat_applies(int N) {
+#ifdef FLEET_NO_FLAT  // experiments only: the grouped mapping for every N
+  return false;
+#else
+  return flat_applies(N);
+#endif
+}
 
 hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs, hipStream_t s) {
 #define CALL(Gv) launch_reset_g<Gv>(d, mask, obs, s)

@@ -324,7 +324,7 @@ def test_division_by_reciprocal_is_bit_exact():
     reciprocal with a residual correction (fleet_kernels.hip div_rcp).  2^30 pseudo-random operand pairs of the charge
     arithmetic's ranges -- incl. +-0 and a 7e-18-sized residue -- against the IEEE division sequence on the device: not one
     quotient may differ in any bit."""
-    lib = _capi.load()
+    lib = _capi.load_library()
     bad = (C.c_uint64 * 2)()
     assert lib.fleet_selftest_division(0, 1 << 30, 12345, bad) == 0
     assert (bad[0], bad[1]) == (0, 0), f"quotients that differ from the IEEE division: need/eta {bad[0]}, energy/cap {bad[1]}"
