@@ -410,7 +410,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
   d.aux = p->aux; d.normalize = p->normalize; d.is_caretaker = p->is_caretaker; d.deg_mode = p->deg_mode;
   d.auto_reset = p->auto_reset;
   d.real_time = p->real_time ? 1 : 0;
-  d.flat_step = fleet_flat_applies(N) ? 1 : 0;
+  d.carry_run = (N <= fleet_max_evs_per_lane_group()) ? 1 : 0;
   d.dt = p->dt; d.evse_power = p->evse_power;
   d.p_avail = p->obc_max_power < p->evse_power ? p->obc_max_power : p->evse_power;  // min([obc, evse]) ev_charger.py:95
   d.init_cap = p->init_battery_cap; d.grid_connection = p->grid_connection;

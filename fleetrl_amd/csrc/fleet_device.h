@@ -200,7 +200,8 @@ struct FleetDev {
   int tail_stride;  // floats per tail row (tail_a then tail_b, padded to a multiple of 4)
   int aux, normalize, is_caretaker, deg_mode, auto_reset;
   int real_time;    // event-skipping step (multi-step kernel only)
-  int flat_step;    // single-step launches run the flat kernel (one EV per lane, envs packed densely; fleet_kernels.hip flat_applies)
+  int carry_run;    // single-step launches read the carried schedule records `run` (one EV per lane: N <= fleet_max_evs_per_lane_group()),
+                    // so every kernel that advances the batch leaves them behind -- also the K-step kernels of a batch with N > 64
   // ---- hot scalars (FleetParams) ------------------------------------------------------------------------
   double dt, p_avail, init_cap, eta_c, eta_d, penalty_invalid, penalty_oc, clip_oc, target_soc, target_soc_lunch, eps,
       fully_charged_reward, evse_power, grid_connection, penalty_overload, max_time_left, stress_temp;
@@ -244,7 +245,7 @@ struct FleetDev {
 
 // launchers implemented in fleet_kernels.hip
 hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs, hipStream_t s);
-bool fleet_flat_applies(int N);  // whether single-step launches of an N-EV batch use the flat kernel
+int fleet_max_evs_per_lane_group();  // up to this many EVs per env the single-step kernel gives every EV a lane (fleet_kernels.hip kMaxGroup)
 hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                              uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s);
 // compact the terminal observations of the envs with done[e] != 0 (env order): idx[k], *count, compact[k, obs_dim]

@@ -40,7 +40,7 @@
 #ifdef FLEET_STAMPS
 // Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave (the first 4096) at fixed points of the step,
 // written to a buffer nothing else reads.  Never compiled into the product library.
-__device__ unsigned long long fleet_stamp_buf[4096 * 16];
+__device__ unsigned long long fleet_stamp_buf[4096 * 32];
 #define FLEET_STAMP(k)                                                                                   \
   do {                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -48,7 +48,7 @@ __device__ unsigned long long fleet_stamp_buf[4096 * 16];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                           \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
     const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
-    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 16 + (k)] = _t;                       \
+    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 32 + (k)] = _t;                       \
   } while (0)
 // wall-clock stamps (s_memrealtime: 100 MHz, one counter for the whole chip) at a wave's entry (slot 9) and exit (slot 10):
 // the launch's timeline across dies, which the per-die shader-clock stamps cannot give
@@ -56,7 +56,19 @@ __device__ unsigned long long fleet_stamp_buf[4096 * 16];
   do {                                                                                                   \
     const unsigned long long _t = __builtin_amdgcn_s_memrealtime();                                      \
     const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
-    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 16 + (k)] = _t;                       \
+    if ((threadIdx.x & 63) == 0 && _w < 4096) fleet_stamp_buf[_w * 32 + (k)] = _t;                       \
+  } while (0)
+// where the wavefront runs (slot 16: HW_REG_HW_ID = wave / SIMD / CU / SH / SE ids; slot 17: HW_REG_XCC_ID): does the tail of slow
+// wavefronts belong to a die, a CU, a SIMD?
+#define FLEET_STAMP_WHERE()                                                                              \
+  do {                                                                                                   \
+    const unsigned _hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));                         \
+    const unsigned _xc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));                        \
+    const unsigned _w = blockIdx.x * (FLEET_KBLOCK / 64) + threadIdx.x / 64;                             \
+    if ((threadIdx.x & 63) == 0 && _w < 4096) {                                                          \
+      fleet_stamp_buf[_w * 32 + 16] = _hw;                                                               \
+      fleet_stamp_buf[_w * 32 + 17] = _xc;                                                               \
+    }                                                                                                    \
   } while (0)
 extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fleet_stamp_buf), sizeof(fleet_stamp_buf));
@@ -64,6 +76,7 @@ extern "C" int fleet_debug_read_stamps(unsigned long long* out) {
 #else
 #define FLEET_STAMP(k) do {} while (0)
 #define FLEET_STAMP_RT(k) do {} while (0)
+#define FLEET_STAMP_WHERE() do {} while (0)
 #endif
 
 namespace {
@@ -78,6 +91,12 @@ constexpr int kSingleWaves = 4, kMultiWaves = 4, kMultiWideWaves = 2;
 #define FLEET_KBLOCK 256  // (a macro only because the diagnostic stamp code above indexes its buffer with it)
 #endif
 constexpr int kBlock = FLEET_KBLOCK;  // threads per workgroup
+// Largest lane group of one env in the single-step kernel: up to this many EVs every EV has a lane of its own.  Groups above 64
+// lanes are two or four WAVEFRONTS of one workgroup: every wavefront reduces its lanes' terms as a one-wavefront env does, the
+// per-wavefront partial sums meet in the LDS behind one workgroup barrier, and the group's last lane adds them up (round 5: the
+// c5 shard's 200-EV envs as 4 wavefronts x 1 EV per lane instead of 1 wavefront x 4 EVs per lane walked one after the other).
+constexpr int kMaxGroup = 256;
+static_assert(kMaxGroup <= kBlock && kBlock % 64 == 0, "a lane group is a whole number of a workgroup's wavefronts");
 
 // ---------------------------------------------------------------------------------------------------------
 // wavefront helpers
@@ -98,7 +117,7 @@ __device__ __forceinline__ double dpp_add(double v) {
 template <int G>
 __device__ __forceinline__ bool group_any(bool v) {
   const unsigned long long m = __ballot(v);
-  if (G == 64) return m != 0ull;
+  if (G >= 64) return m != 0ull;  // (groups of several wavefronts exist in the single-step kernel only: no event test there)
   const int base = (int)(threadIdx.x % 64) & ~(G - 1);
   return ((m >> base) & ((1ull << (G % 64)) - 1ull)) != 0ull;
 }
@@ -651,8 +670,8 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
 // reset of one env by its group (FleetEnv.reset, fleet_environment.py:330-434)
 // ---------------------------------------------------------------------------------------------------------
 // FleetEnv.reset in two parts -- what each EV of the env does for itself, and what is done once per env -- so that both lane
-// mappings can use them (a group of G lanes per env: reset_env below; one EV per lane with the envs packed densely: the flat step
-// kernel, where the env's part is run by another thread than its EVs').
+// parts can be placed independently (reset_env below runs them for a group of G lanes; round 5's flat-mapping experiment ran the
+// env's part on another thread than its EVs').
 // The EV's part (fleet_environment.py:345-399): state of health, SOC / hours_left from the start row, laxity fix-up, first SOC
 // sample, the carried schedule record, the observation slots.  `log_obs_row` / `log_ev_soh`: the data log's row reset() writes.
 __device__ __forceinline__ void reset_ev(const FleetDev& d, int e, int c, int start, float* __restrict__ obs_row,
@@ -946,7 +965,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
   int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
-  if (G == 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
+  if (G >= 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
   const bool env_ok = e_raw < E_;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
   const int e = env_ok ? e_raw : E_ - 1;
 
@@ -976,7 +995,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   }
 
   EnvHead r = p_env[e].h;
-  if (G == 64) {
+  if (G >= 64) {
     r.t = __builtin_amdgcn_readfirstlane(r.t);
     r.t_end = __builtin_amdgcn_readfirstlane(r.t_end);
     r.nsamp = __builtin_amdgcn_readfirstlane(r.nsamp);
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   int night_st = FLEET_NIGHT_IDLE;
   if (MULTI && act_mode == FLEET_ACT_POLICY_NIGHT) {
     night_st = d.cold->night_start[e];
-    if (G == 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
+    if (G >= 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
   }
 
   // data log cursor of the env (rows written so far), carried in a register over the launch's steps.  The logging code lives
@@ -1012,7 +1031,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   static_assert(!LOG || MULTI, "the data log is compiled into the multi-step kernel only");
   constexpr bool log_on = LOG;
   int lp = log_on ? d.log_pos[e] : 0;
-  if (G == 64) lp = __builtin_amdgcn_readfirstlane(lp);
+  if (G >= 64) lp = __builtin_amdgcn_readfirstlane(lp);
 
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
@@ -1069,7 +1088,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     const bool deg_row = (DEG != FLEET_DEG_NONE) && (flags1 & FLEET_TFLAG_DEG);
     // the few wavefronts with extra work after the step (daily evaluation, episode end + reset) finish last and set the
     // launch's duration: they get issue priority over their SIMD's other wavefronts for the step itself (-3 % per launch)
-    if (!MULTI && G == 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
+    if (!MULTI && G >= 64 && ((DEG == FLEET_DEG_RAINFLOW && deg_row) || is_done)) __builtin_amdgcn_s_setprio(3);
     const size_t abase = ((size_t)(rt ? 0 : k) * d.E + e) * N;
 
     // data log: the step's row (not written for the step that ends the episode, :679) -- its observation goes to the log's own
@@ -1245,8 +1264,36 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
     FLEET_STAMP(6);
     // ---- per-env reductions; totals land in the leader lane ---------------------------------------------------
-    if (G == 64) {
-      wave_sum4_to_last(cash, rew, asum, penrec);
+    if (G >= 64) {
+      wave_sum4_to_last(cash, rew, asum, penrec);  // this wavefront's lanes: totals in its last lane
+      if (G > 64) {
+        // an env of several wavefronts: their partial sums meet in the LDS and the group's last lane adds them in wavefront order
+        static_assert(G <= 64 || !MULTI, "wavefronts of a K-step launch advance independently: no workgroup barrier inside the step");
+        __shared__ double s_part[kBlock / 64][4];
+        const int w = (int)threadIdx.x / 64;
+        if ((threadIdx.x & 63) == 63) {
+          s_part[w][0] = cash;
+          s_part[w][1] = rew;
+          s_part[w][2] = asum;
+          s_part[w][3] = penrec;
+        }
+        __syncthreads();
+        if (leader) {
+          const int w0 = ((int)threadIdx.x / G) * (G / 64);
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+          for (int k = 0; k < G / 64; ++k) {
+            s0 += s_part[w0 + k][0];
+            s1 += s_part[w0 + k][1];
+            s2 += s_part[w0 + k][2];
+            s3 += s_part[w0 + k][3];
+          }
+          cash = s0;
+          rew = s1;
+          asum = s2;
+          penrec = s3;
+        }
+      }
     } else {
       cash = group_sum_to_last<G>(cash);
       rew = group_sum_to_last<G>(rew);
@@ -1355,9 +1402,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
   {  // ---- after the steps: again through the freshly read block ----
   const FleetDev& d = late_args();
-  // (only where a single-step launch that reads them can follow on the same handle: with more EVs than lanes the grouped kernels
-  // read the table -- unless the handle's single steps run the flat kernel, which carries the records like the narrow one)
-  if (!kEarly && (!WIDE || d.flat_step) && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
+  // (only where a single-step launch that reads them can follow on the same handle: `carry_run`, i.e. up to kMaxGroup EVs per env)
+  if (!kEarly && (!WIDE || d.carry_run) && env_ok) {  // the carried schedule records: the row the NEXT launch advances to
     const int rn = r.t + 1 > d.T - 1 ? d.T - 1 : r.t + 1;
     for (int c = g; c < N; c += G) d.run[(size_t)e * N + c] = d.seg[(size_t)rn * N + c];
   }
@@ -1386,223 +1432,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   }  // late_args scope
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The step with the envs packed densely into the workgroup: ONE EV PER LANE for any number of EVs per env, lane l of a workgroup
-// that holds `epw` envs owns EV (l mod N) of env (l div N) -- 5 envs of 50 EVs in 256 lanes (250 busy), 5 envs of 200 EVs in 1024
-// (1000 busy) -- instead of a power-of-two group of lanes per env (50 EVs: 64 lanes, 78 % busy; 200 EVs: 64 lanes walking four
-// EVs each, one after the other).  An env's lanes may straddle wavefronts, so the four per-env sums go through the LDS: every
-// lane stores its four terms (one plane per quantity), the workgroup meets at one barrier, and 16 lanes per env -- four per
-// quantity -- add the env's terms up; the last of the sixteen is the env's LEADER and does what is done once per env: overload
-// penalty, episode bookkeeping, reward / done, the head of the env's record.  The leader is not one of the env's EV lanes in
-// general: it reads the env's record and the time row's physics scalars for itself when the launch starts.
-// One step per launch, no data log, no real_time (those run the grouped kernel's multi-step form).
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double quad_sum(double v) {  // sum over the lane's aligned quad, valid in all four lanes
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true));  // quad_perm:[1,0,3,2]
-  lo = __double2loint(v), hi = __double2hiint(v);
-  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true));  // quad_perm:[2,3,0,1]
-  return v;
-}
-template <int SHR>
-__device__ __forceinline__ double row_from(double v) {  // the value of the lane SHR places down the 16-lane row (row_shr:SHR)
-  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + SHR, 0xF, 0xF, true),
-                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + SHR, 0xF, 0xF, true));
-}
-
-template <int DEG, bool A64>
-__global__ __launch_bounds__(1024) void fleet_step_flat_kernel(
-    // (the same leading arguments as fleet_step_kernel: preloaded into scalar registers at wave launch)
-    const Hot* p_hot, const SegRec* p_run, const double* p_soh, const void* __restrict__ p_actions, int p_E, int p_N, EnvRec* p_env,
-    FleetDev d, int epw, uint32_t magic, float* __restrict__ obs, double* __restrict__ reward, uint8_t* __restrict__ done,
-    float* __restrict__ terminal_obs) {
-  extern __shared__ double flat_lds[];  // [4][blockDim.x]: cashflow, reward, sum(action * there), penalty record terms
-  const int N = p_N, E_ = p_E;
-  const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
-  // ---- the lane as an EV ----
-  const int el = (int)(((uint32_t)tid * magic) >> 20);  // tid / N (exact for tid < 1024, N < 1024: fleet_launch_step checks)
-  const int c = tid - el * N;
-  const int e_raw = (int)blockIdx.x * epw + el;
-  const bool ev_ok = (el < epw) && (e_raw < E_);  // surplus lanes run the arithmetic on the last env's EV and store nothing
-  const int e = e_raw < E_ ? e_raw : E_ - 1;
-  const EvIx i = {(size_t)e * N, (unsigned)c};
-  const size_t f0 = i.flat();
-  const Hot hb = p_hot[f0];
-  const double soh0 = p_soh[f0];
-  double a64_pre = 0.0;
-  float a32_pre = 0.0f;
-  if (A64) a64_pre = ((const double*)p_actions)[f0];
-  else a32_pre = ((const float*)p_actions)[f0];
-  const SegRec rr = p_run[f0];
-  EnvHead r = p_env[e].h;
-  // ---- the lane as an env's leader (the last of the env's sixteen reducer lanes) ----
-  const int jl = tid >> 4;
-  const int e_led = (int)blockIdx.x * epw + jl;
-  const bool leads = ((tid & 15) == 15) && (jl < epw) && (e_led < E_);
-  EnvHead rl = {0, 0, 0, 0};
-  double ep_return = 0.0, penalty_record = 0.0, l_load = 0.0, l_pv = 0.0;
-  int ep_len = 0;
-  uint32_t l_flags_after = 0;
-  if (leads) {
-    const EnvRec* er = p_env + e_led;
-    rl = er->h;
-    ep_return = er->ep_return;
-    penalty_record = er->penalty_record;
-    ep_len = er->ep_len;
-  }
-
-  const uint32_t head_flags = HEAD_FLAGS(r.nsamp);  // FLEET_TFLAG_* of row t + 1, left by the previous launch
-  r.nsamp = HEAD_NSAMP(r.nsamp);
-  uint32_t err = 0;
-  const int t = r.t;
-  int t1 = t + 1;  // :508
-  if (t1 > d.T - 1) { t1 = d.T - 1; err |= FLEET_DEVERR_TABLE_END; }
-  const int t2 = t1 + 1 > d.T - 1 ? d.T - 1 : t1 + 1;  // the row the NEXT step advances to
-  const bool is_done = (t + 1 == r.t_end);  // :627-628
-  const bool resets = is_done && d.auto_reset;
-  float* const obs_row = obs + (size_t)e * d.obs_dim;
-  float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
-  float* const step_row = resets ? term_row : obs_row;  // with vec-env auto-reset the terminal observation is reported aside
-  const bool write_step_obs = ev_ok && (step_row != nullptr);
-  // time-row loads, consumed late: the physics record (money terms) and the lane's words of the observation tail
-  const PhysHot ph = *reinterpret_cast<const PhysHot*>(d.tab_phys + t);
-  const int tail_total = d.tail_a_len + d.tail_b_len;
-  const float tail_first = (c < tail_total) ? d.tab_tail[(size_t)t1 * d.tail_stride + c] : 0.0f;
-  if (leads) {
-    const int tl = rl.t;
-    const int tl1 = tl + 1 > d.T - 1 ? d.T - 1 : tl + 1;
-    const PhysHot* pl = reinterpret_cast<const PhysHot*>(d.tab_phys + tl);
-    l_load = pl->load;
-    l_pv = pl->pv;
-    l_flags_after = reinterpret_cast<const PhysHot*>(d.tab_phys + tl1)->flags_next;
-  }
-  const double dt_step = d.dt;
-  const bool lunch = d.is_caretaker && (head_flags & FLEET_TFLAG_LUNCH);
-  const bool deg_row = (DEG != FLEET_DEG_NONE) && (head_flags & FLEET_TFLAG_DEG);
-
-  // ---- the EV's step (as in fleet_step_kernel, one EV per lane) ----
-  const bool inplane = HOT_INPLANE(hb.bits);
-  double old_deg = hb.x;
-  if (inplane) old_deg = d.soc_deg[f0];
-  const double a = A64 ? a64_pre : (double)a32_pre;
-  const bool crosses = (t1 + 1 >= SEG_END(rr.se));
-  SegRec nr = rr;
-  if (crosses) nr = d.seg[(size_t)t2 * N + c];
-  const RowRec tb1 = seg_row(rr, t1, d.dt);
-  const EvPhys pe = ev_physics<false>(d, hb, old_deg, tb1, soh0, a, dt_step, lunch);
-  int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
-  RfReq rq;
-  rq.push = false;
-  rq.win = false;
-  if (DEG == FLEET_DEG_RAINFLOW && ev_ok) rf_begin(d, i, old_deg, pe.soc_deg, tail, sgn, rq);
-  const double tgt_obs = pe.t090 ? 0.9 : d.target_soc;  // the target the observer sees: after this step's sticky update
-  if (write_step_obs) write_obs_ev(d, step_row, c, pe.soc, pe.hl, tgt_obs, tb1);
-  double cash, rew = pe.rew;
-  {
-    const double grid_e = fmax(pe.en - ph.pv_share, 0.0);  // :142 (charging only)
-    cash = pe.pos ? -(grid_e * ph.k_cost) : pe.en * ph.k_rev;       // -charging_cost :149 / +discharging_revenue :196-199
-    rew += pe.pos ? ph.k_charge * grid_e : ph.k_discharge * pe.en;  // :154-156 / :204-206
-  }
-  double sei_sample = 0.0, sei_soh = 0.0;
-  int sei_tail = 0;
-  RfTop sei_top = {0.0, 0.0};
-  bool sei_have_top = false;
-  RfAccHead acc_c = {0.0, 0, 0};
-  RfTop top_c = {0.0, 0.0};
-  ev_finish<DEG, false>(d, i, c, N, ev_ok, deg_row, dt_step, rq, tail, sgn, pe.soc, pe.soc_deg, old_deg, pe.hl, tb1.there, pe.t090, inplane,
-                        crosses, nr, soh0, a, pe.en, false, 0, hb, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c, top_c,
-                        false);
-  // the env-level observation blocks: lane c copies tail word c, c + N, ... of the row the step advanced to
-  if (write_step_obs) {
-    const int na = d.tail_a_len;
-    const unsigned base_a = 2u * (unsigned)N, base_b = 7u * (unsigned)N;  // block B: 2N + na + 5N + (j - na) = 7N + j
-    if (c < tail_total) st_obs(step_row + ((c < na ? base_a : base_b) + (unsigned)c), tail_first);
-    for (int j = c + N; j < tail_total; j += N) step_row[(j < na ? base_a : base_b) + (unsigned)j] = d.tab_tail[(size_t)t1 * d.tail_stride + j];
-  }
-  if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
-
-  // ---- the four per-env terms of this EV go to the LDS (a lane that owns no EV contributes nothing) ----
-  flat_lds[tid] = ev_ok ? cash : 0.0;
-  flat_lds[nthr + tid] = ev_ok ? rew : 0.0;
-  flat_lds[2 * nthr + tid] = ev_ok ? pe.a_th : 0.0;
-  flat_lds[3 * nthr + tid] = ev_ok ? pe.penrec : 0.0;
-
-  // ---- daily SEI evaluation (:666-671), the EV's own ----
-  if (DEG == FLEET_DEG_RAINFLOW && deg_row && ev_ok) {
-    const double deg = sei_evaluate(*d.self, i, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step, nullptr);
-    d.soh[f0] = sei_soh - deg;
-  }
-  // ---- episode end: the EV's part of the auto-reset ----
-  if (resets && ev_ok) {
-    r.episodes += 1;
-    const int start = reset_times(*d.self, e, r);
-    reset_ev(*d.self, e, c, start, obs_row, nullptr, nullptr);
-    const int na = d.tail_a_len;
-    const unsigned base_a = 2u * (unsigned)N, base_b = 7u * (unsigned)N;
-    for (int j = c; j < tail_total; j += N) obs_row[(j < na ? base_a : base_b) + (unsigned)j] = d.tab_tail[(size_t)start * d.tail_stride + j];
-  }
-  if (err && ev_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
-    atomicOr(&d.env[e].err, err);
-    atomicOr(d.self->err_any, err);
-  }
-
-  __syncthreads();
-  // ---- per-env sums: lane k of the env's sixteen adds every fourth term of quantity k / 4, the quad finishes it ----
-  if (jl < epw) {
-    const int q = (tid >> 2) & 3, k4 = tid & 3;
-    const double* src = flat_lds + q * nthr + jl * N;
-    double sum = 0.0;
-    for (int m = k4; m < N; m += 4) sum += src[m];
-    sum = quad_sum(sum);
-    // lanes 3, 7, 11, 15 of the row hold cashflow, reward, sum(action * there), penalty record: bring them to lane 15
-    const double s_cash = row_from<12>(sum), s_rew = row_from<8>(sum), s_asum = row_from<4>(sum), s_pen = sum;
-    if (leads) {
-      const int el_ = e_led;
-      const int tl = rl.t;
-      int tl1 = tl + 1;
-      if (tl1 > d.T - 1) tl1 = d.T - 1;
-      const bool l_done = (tl + 1 == rl.t_end);
-      double rew_e = s_rew;
-      penalty_record += s_pen;
-      // LoadCalculation.check_violation (load_calculation.py:93) and the sigmoid penalty (:496-502)
-      const double head_room = d.grid_connection - l_load - s_asum * d.evse_power + l_pv;
-      const double over = fabs(head_room < 0.0 ? head_room : 0.0);
-      if (over > 0.0) {
-        const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
-        rew_e += pen;
-        penalty_record += pen;
-      }
-      ep_return += rew_e;  // :637
-      ep_len += 1;
-      EnvRec* er = d.env + el_;
-      er->cashflow = s_cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
-      reward[el_] = rew_e;
-      done[el_] = l_done ? 1 : 0;
-      int nsamp = HEAD_NSAMP(rl.nsamp);
-      if (DEG != FLEET_DEG_NONE) nsamp += 1;
-      rl.t = tl1;
-      if (l_done) {
-        er->last_ep_return = ep_return;
-        er->last_ep_len = ep_len;
-        rl.episodes += 1;
-        if (d.auto_reset) {
-          const int start = reset_times(*d.self, el_, rl);
-          reset_head(*d.self, el_, rl, start);
-        } else {
-          er->start_done |= (int32_t)0x80000000u;  // episode.done
-        }
-      }
-      if (!(l_done && d.auto_reset)) {
-        rl.nsamp = HEAD_PACK(nsamp, l_flags_after);  // the head carries the row flags the next launch's state machine needs
-        er->h = rl;
-        er->ep_return = ep_return;
-        er->ep_len = ep_len;
-        er->penalty_record = penalty_record;
-      }
-    }
-  }
+  FLEET_STAMP_WHERE();
 }
 
 // FleetEnv.get_dist_factor (fleet_environment.py:782-799)
@@ -1743,33 +1573,6 @@ int group_size(int N) {
   return G;
 }
 
-// Workgroup geometry of the flat step kernel for N EVs per env: W wavefronts holding epw = (64 W) div N whole envs.  The fullest
-// workgroup wins; among equally full ones the smallest (its barrier joins fewer wavefronts).
-struct FlatGeom {
-  int waves, epw;
-};
-FlatGeom flat_geom(int N) {
-  FlatGeom best = {0, 0};
-  double best_fill = 0.0;
-#ifdef FLEET_FLAT_W  // experiments only (tools/r05_build_variants.sh): a fixed workgroup size
-  for (int W = FLEET_FLAT_W; W <= FLEET_FLAT_W; ++W) {
-#else
-  for (int W = (N <= 64 ? 4 : (N + 63) / 64); W <= 16; W += (N <= 64 ? 4 : 1)) {
-#endif
-    const int epw = (64 * W) / N;
-    if (epw < 1) continue;
-    const double fill = (double)(epw * N) / (64.0 * W);
-    if (fill > best_fill + 1e-9) {
-      best_fill = fill;
-      best = {W, epw};
-    }
-  }
-  return best;
-}
-// One EV per lane pays where the grouped mapping leaves lanes idle or walks several EVs per lane: N > 64, or N between two
-// powers of two (profiles/r05_experiments/flat_*.log).  Small fleets (N <= 16) keep their power-of-two groups.
-bool flat_applies(int N) { return N > 16 && N < 1024 && (N > 64 || (N & (N - 1)) != 0); }
-
 template <int G, int DEG>
 hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
@@ -1779,17 +1582,25 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
-  if (single && d.flat_step && G >= 32) {
-    const FlatGeom fg = flat_geom(d.N);
-    const dim3 fgrid((d.E + fg.epw - 1) / fg.epw), fblock(64 * fg.waves);
-    const size_t lds = (size_t)4 * 64 * fg.waves * sizeof(double);
-    const uint32_t magic = (1u << 20) / (uint32_t)d.N + 1u;
-    if (f64 == FLEET_ACT_F64)
-      hipLaunchKernelGGL((fleet_step_flat_kernel<DEG, true>), fgrid, fblock, lds, s, FLEET_PRE_ARGS d, fg.epw, magic, obs, reward, done,
-                         terminal_obs);
-    else
-      hipLaunchKernelGGL((fleet_step_flat_kernel<DEG, false>), fgrid, fblock, lds, s, FLEET_PRE_ARGS d, fg.epw, magic, obs, reward, done,
-                         terminal_obs);
+  if (G == 64 && single && d.N > 64 && d.N <= kMaxGroup) {  // one EV per lane, two or four wavefronts per env
+    constexpr int GG2 = (G == 64) ? 128 : G, GG4 = (G == 64) ? 256 : G;  // (only instantiated behind G == 64)
+    if (d.N <= 128) {
+      const dim3 g2((d.E + 1) / 2);
+      if (f64 == FLEET_ACT_F64)
+        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, false, false, false, true>), g2, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
+                           reward, done, terminal_obs, done_count);
+      else
+        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, false, false>), g2, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
+                           terminal_obs, done_count);
+    } else {
+      const dim3 g4(d.E);
+      if (f64 == FLEET_ACT_F64)
+        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, false, false, false, true>), g4, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
+                           reward, done, terminal_obs, done_count);
+      else
+        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, false, false>), g4, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
+                           terminal_obs, done_count);
+    }
     return hipGetLastError();
   }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
@@ -1849,13 +1660,9 @@ hipError_t launch_reset_g(const FleetDev& d, const uint8_t* mask, float* obs, hi
     default: return CALL(64);              \
   }
 
-bool fleet_flat_applies(int N) {
-#ifdef FLEET_NO_FLAT  // experiments only: the grouped mapping for every N
-  return false;
-#else
-  return flat_applies(N);
-#endif
-}
+// Up to this many EVs per env a single-step launch gives every EV a lane of its own (groups of 1 ... 4 wavefronts per env) and reads
+// the carried schedule records; beyond it the lanes walk several EVs each and read the table.
+int fleet_max_evs_per_lane_group() { return kMaxGroup; }
 
 hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs, hipStream_t s) {
 #define CALL(Gv) launch_reset_g<Gv>(d, mask, obs, s)

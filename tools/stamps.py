@@ -38,10 +38,11 @@ b.run_tape_dev(2000 if _n > 4000 else _n, tape.data_ptr(), 16, obs.data_ptr(), r
 b.synchronize()
 print("launch period (eager, stamped build): %.2f us" % ((_time.perf_counter() - _t0) * 1e6 / (2000 if _n > 4000 else _n)))
 lib = _capi.load_library()
-buf = np.zeros(4096 * 16, dtype=np.uint64)
+SLOTS = 32
+buf = np.zeros(4096 * SLOTS, dtype=np.uint64)
 lib.fleet_debug_read_stamps.argtypes = [C.c_void_p]
 assert lib.fleet_debug_read_stamps(buf.ctypes.data) == 0
-s = buf.reshape(4096, 16)[: min(E, 4096), :9].astype(np.int64)  # one row per wavefront (G = 64: one env each)
+s = buf.reshape(4096, SLOTS)[: min(E, 4096), :9].astype(np.int64)  # one row per wavefront (G = 64: one env each)
 valid = (s > 0).all(axis=1)
 s = s[valid]
 names = ["entry->env head ready", "stage-2 issue + hot loads ready", "charge + state machine", "observation stores",
@@ -59,7 +60,7 @@ for name, sel in (("ordinary", ~long), ("long", long)):
         print(f"  {name:9s} last segment median {np.median(d[sel, 7]):8.0f}  p90 {np.percentile(d[sel, 7], 90):8.0f}   total median "
               f"{np.median(tot[sel]):8.0f}  p90 {np.percentile(tot[sel], 90):8.0f}")
 # inside the daily rainflow pass (stamps 11, 14, 15, 12, 13 are only written by the wavefronts on the 14:45 row)
-full = buf.reshape(4096, 16)[: min(E, 4096)].astype(np.int64)
+full = buf.reshape(4096, SLOTS)[: min(E, 4096)].astype(np.int64)
 sel = (full[:, 11] > full[:, 7]) & (full[:, 13] > full[:, 11]) & (full[:, 8] > full[:, 13]) & (full[:, 8] - full[:, 7] < 10**6)
 if sel.any():
     f = full[sel]
@@ -74,7 +75,7 @@ if sel.any():
           {k: (int(np.median(v)), int(np.percentile(v, 90)), int(v.max())) for k, v in seg.items()}, "(median, p90, max cycles)")
 
 # the launch's timeline from the chip-wide 100 MHz counter (10 ns ticks)
-rt = buf.reshape(4096, 16)[: min(E, 4096), 9:11].astype(np.int64)
+rt = buf.reshape(4096, SLOTS)[: min(E, 4096), 9:11].astype(np.int64)
 rt = rt[(rt > 0).all(axis=1)]
 t0 = rt[:, 0].min()
 us = lambda x: round(float(x) / 100.0, 2)  # noqa: E731
@@ -83,7 +84,7 @@ print("launch timeline [us from the first wave's entry]: wave entry median / p90
       [us(np.percentile(rt[:, 1], q) - t0) for q in (10, 50, 90, 99, 100)], " wave life median / p90 / max",
       [us(np.percentile(rt[:, 1] - rt[:, 0], q)) for q in (50, 90, 100)])
 # who finishes last: the 24 latest exits of the launch, by kind of extra work after the step
-rt_all = buf.reshape(4096, 16)[: min(E, 4096)].astype(np.int64)
+rt_all = buf.reshape(4096, SLOTS)[: min(E, 4096)].astype(np.int64)
 ok = (rt_all[:, 9] > 0) & (rt_all[:, 10] > 0)
 t0 = rt_all[ok, 9].min()
 late = np.argsort(np.where(ok, rt_all[:, 10], 0))[-24:][::-1]
@@ -137,3 +138,48 @@ if cw.any():
     for a_, b_, n_ in zip(order[:-1], order[1:], names2[1:]):
         dlt = f[:, b_] - f[:, a_]
         print(f"   -> {n_:52s} {int(np.median(dlt)):7d}  p90 {int(np.percentile(dlt, 90)):7d}  max {int(dlt.max()):7d}")
+
+
+# ---- where the slow wavefronts run (round 5): slot 16 = HW_REG_HW_ID, 17 = HW_REG_XCC_ID -------------------------
+hw = rt_all[:, 16]
+if (hw != 0).any():
+    simd, cu, sh, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, rt_all[:, 17] & 15
+    life = (rt_all[:, 10] - rt_all[:, 9]) / 100.0
+    exit_us = (rt_all[:, 10] - t0) / 100.0
+    entry_us = (rt_all[:, 9] - t0) / 100.0
+    m = ok & (cls == 0)
+    cu_key = xcc * 10000 + se * 1000 + sh * 100 + cu
+    simd_key = cu_key * 10 + simd
+    import collections
+    per_cu = collections.Counter(cu_key[ok].tolist())
+    per_simd = collections.Counter(simd_key[ok].tolist())
+    print("wavefronts per CU:", dict(collections.Counter(per_cu.values())), " per SIMD:", dict(collections.Counter(per_simd.values())),
+          " CUs used:", len(per_cu))
+    print("plain wavefronts, life [us] by die (XCC):", {int(x): (int((m & (xcc == x)).sum()), round(float(np.median(life[m & (xcc == x)])), 2),
+          round(float(life[m & (xcc == x)].max()), 2)) for x in np.unique(xcc[m])}, "(n, median, max)")
+    nw_cu = np.array([per_cu[k] for k in cu_key.tolist()])
+    nw_simd = np.array([per_simd[k] for k in simd_key.tolist()])
+    for name, arr in (("wavefronts on its CU", nw_cu), ("wavefronts on its SIMD", nw_simd)):
+        print("plain wavefronts, life [us] by", name + ":", {int(v): (int((m & (arr == v)).sum()), round(float(np.median(life[m & (arr == v)])), 2),
+              round(float(np.percentile(life[m & (arr == v)], 90)), 2), round(float(exit_us[m & (arr == v)].max()), 2)) for v in np.unique(arr[m])}, "(n, median, p90, last exit)")
+    # is the tail a property of the CU?  spread of the per-CU median life, and the CUs of the 40 latest exits
+    cu_med = {k: float(np.median(life[m & (cu_key == k)])) for k in per_cu if (m & (cu_key == k)).any()}
+    v = np.array(list(cu_med.values()))
+    print("median life per CU [us]: p10 %.2f p50 %.2f p90 %.2f max %.2f" % (*np.percentile(v, [10, 50, 90]), v.max()))
+    late = np.argsort(np.where(m, exit_us, 0))[-40:][::-1]
+    print("the 40 latest plain exits: (exit us, entry us, die, SE, CU, SIMD, wavefronts on its CU / SIMD, daily-row or reset wavefronts on its SIMD)")
+    heavy_simd = collections.Counter(simd_key[ok & (cls != 0)].tolist())
+    for w in late:
+        print("   %.2f  %.2f  xcc %d se %d cu %2d simd %d   %d / %d   %d" % (exit_us[w], entry_us[w], xcc[w], se[w], sh[w] * 16 + cu[w], simd[w], nw_cu[w], nw_simd[w],
+                                                                       heavy_simd.get(int(simd_key[w]), 0)))
+    with_heavy = np.array([heavy_simd.get(int(k), 0) > 0 for k in simd_key.tolist()])
+    for name, sel in (("shares its SIMD with a daily-row / reset wavefront", m & with_heavy), ("does not", m & ~with_heavy)):
+        if sel.any():
+            print("plain wavefronts whose SIMD %-52s n %5d life median %.2f p90 %.2f max %.2f  last exit %.2f" %
+                  (name, sel.sum(), np.median(life[sel]), np.percentile(life[sel], 90), life[sel].max(), exit_us[sel].max()))
+    # entry time against exit time: do the late starters end the launch?
+    q = np.argsort(entry_us[m])
+    ee, xx = entry_us[m][q], exit_us[m][q]
+    n4 = len(ee) // 4
+    print("plain wavefronts by entry quartile: entry median -> exit median / max:", [(round(float(np.median(ee[i * n4:(i + 1) * n4])), 2),
+          round(float(np.median(xx[i * n4:(i + 1) * n4])), 2), round(float(xx[i * n4:(i + 1) * n4].max()), 2)) for i in range(4)])
