@@ -81,7 +81,9 @@ def kernel_name(n_evs: int, deg: str) -> str:
     g = 1
     while g < n_evs and g < 64:
         g <<= 1
-    return (f"fleet_step_kernel<G={g},DEG={deg},MULTI=false,WIDE={'true' if n_evs > 64 else 'false'}>")
+    if 64 < n_evs <= 256:  # groups of two / four wavefronts per env, one EV per lane (kMaxGroup)
+        g = 128 if n_evs <= 128 else 256
+    return (f"fleet_step_kernel<G={g},DEG={deg},MULTI=false,WIDE={'true' if n_evs > 256 else 'false'}>")
 
 
 def kernel_source_sha() -> str:
@@ -94,9 +96,9 @@ def kernel_source_sha() -> str:
 
 def committed_traffic(config: str, envs: int, evs: int):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
-    profiles/r04_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
+    profiles/r05_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
     The counters need rocprofv3, so they cannot be read inside this run: the figure is looked up, and `traffic_source` says so."""
-    for name in (f"r04_traffic_{config}.json", f"r04_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
+    for name in (f"r05_traffic_{config}.json", f"r05_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -221,7 +223,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--tape-len", type=int, default=64)
+    ap.add_argument("--tape-len", type=int, default=None,
+                    help="steps of the device-resident action tape (replayed cyclically); default: as many as fit --tape-mb, 2 ... 64")
+    ap.add_argument("--tape-mb", type=float, default=32.0,
+                    help="size budget of the action tape: it stands in for a policy's output buffer, which a real loop rewrites every "
+                         "step -- a tape far larger than that (64 steps of the c5 shard are 420 MB, more than the 256 MB Infinity "
+                         "Cache) would make the run measure the streaming of its own input")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with --device-index) only exists to smoke-test the multi-rank control "
                          "flow with several ranks on ONE GPU, which RCCL refuses")
@@ -275,8 +282,10 @@ def main():
         spec["groups"] = tuple(uc for uc in spec["groups"] for _ in range(args.split))
     E = args.envs_per_gpu or spec["envs"]
     N = args.evs or spec["evs"]
-    # a graph replays tape_len launches; a run shorter than that replays a graph of its own length
-    L = max(1, min(args.tape_len, args.steps))
+    # action tape: L steps of [E, N] float32 actions, replayed cyclically
+    tape_len = args.tape_len if args.tape_len else max(2, min(64, int(args.tape_mb * 2**20 // (E * N * 4))))
+    L = max(1, min(tape_len, args.steps))
+    graph_len = L * ((64 + L - 1) // L)  # launches per captured graph: whole tape cycles, at least 64 (fleet_run_tape_dev)
     # launches go through a captured hipGraph of L steps; a run shorter than 64 steps launches eagerly (one graph launch costs
     # about as much as six kernel launches on the host: 9.9 vs 9.65 us per step measured for the driver's 20-step regions)
     use_graph = (not args.no_graph) and args.steps >= 64
@@ -434,7 +443,7 @@ def main():
         fleets = "+".join(g.use_case for g in groups)
         traffic, traffic_source = (committed_traffic(args.config, E, N) if not (args.deg or args.use_case)
                                    else (None, "diagnostic override of the workload"))
-        graph_used = use_graph and args.steps >= L
+        graph_used = use_graph and args.steps >= graph_len
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -454,7 +463,8 @@ def main():
                                    f"48 h episodes, random start rows, auto-reset ({spec['what']})",
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
-                       "launch": (f"hipGraph of {L} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
+                       "launch": (f"hipGraph of {graph_len} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
+                       "action_tape": f"{L} steps x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -498,12 +498,7 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
       b->error = "num_cars x episode length: the rainflow rows of one env exceed 4 GiB";
       return FLEET_ERR_INVALID;
     }
-#ifdef FLEET_EXP_RFSTRIDE  // TIMING EXPERIMENT ONLY (rows overlap: results are wrong on purpose)
-    d.rf_row_stride = FLEET_EXP_RFSTRIDE;
-    if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride + (size_t)d.stack_cap + 64, false))) return rc;
-#else
     if ((rc = dev_alloc(b, &d.rf_rows, EN * (size_t)d.rf_row_stride, false))) return rc;
-#endif
     // headers: rainflow_length = 1 (rainflow_sei_degradation.py:57), everything else 0
     RfHdr h0;
     memset(&h0, 0, sizeof h0);
@@ -1179,7 +1174,10 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
   const char* base = static_cast<const char*>(tape);
   int i = 0;
-  if (use_graph && steps >= tape_len) {
+  // the captured graph holds a whole number of tape cycles and at least 64 launches, however short the tape (a short tape must not
+  // turn the replay into many short graphs: every hipGraphLaunch costs the host ~10 us)
+  const int glen = tape_len * ((64 + tape_len - 1) / tape_len);
+  if (use_graph && steps >= glen) {
     const bool stale = !h->graph_exec || h->graph_tape != tape || h->graph_len != tape_len || h->graph_dtype != act_dtype ||
                        h->graph_obs != obs || h->graph_reward != reward || h->graph_done != done;
     if (stale) {
@@ -1189,8 +1187,8 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
       // stream then; the graph itself is launched on the stream in use
       hipStream_t cap = h->stream ? h->stream : h->own_stream;
       HIP_TRY(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-      for (int k = 0; k < tape_len; ++k) {
-        hipError_t e = fleet_launch_step(h->d, base + (size_t)k * row, act_dtype, 1, obs, reward, done, nullptr, nullptr, cap);
+      for (int k = 0; k < glen; ++k) {
+        hipError_t e = fleet_launch_step(h->d, base + (size_t)(k % tape_len) * row, act_dtype, 1, obs, reward, done, nullptr, nullptr, cap);
         if (e != hipSuccess) {
           (void)hipStreamEndCapture(cap, &graph);
           if (graph) (void)hipGraphDestroy(graph);
@@ -1210,7 +1208,7 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
       h->graph_tape = tape; h->graph_len = tape_len; h->graph_dtype = act_dtype;
       h->graph_obs = obs; h->graph_reward = reward; h->graph_done = done;
     }
-    for (; i + tape_len <= steps; i += tape_len) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+    for (; i + glen <= steps; i += glen) HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
   }
   for (; i < steps; ++i)
     HIP_TRY(h, fleet_launch_step(h->d, base + (size_t)(i % tape_len) * row, act_dtype, 1, obs, reward, done, nullptr, nullptr,

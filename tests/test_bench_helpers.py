@@ -37,7 +37,9 @@ def test_committed_traffic_profile_is_well_formed():
 
 def test_kernel_name_follows_the_launcher():
     assert bench.kernel_name(50, "rainflow") == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
-    assert bench.kernel_name(200, "rainflow") == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=true>"
+    assert bench.kernel_name(200, "rainflow") == "fleet_step_kernel<G=256,DEG=rainflow,MULTI=false,WIDE=false>"  # four wavefronts per env
+    assert bench.kernel_name(100, "rainflow") == "fleet_step_kernel<G=128,DEG=rainflow,MULTI=false,WIDE=false>"
+    assert bench.kernel_name(300, "rainflow") == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=true>"
     assert bench.kernel_name(5, "linear") == "fleet_step_kernel<G=8,DEG=linear,MULTI=false,WIDE=false>"
 
 
@@ -50,12 +52,12 @@ def test_committed_traffic_only_counts_for_the_kernel_it_was_profiled_on(tmp_pat
     for f in ("fleet_kernels.hip", "fleet_device.h"):
         (tmp_path / "fleetrl_amd" / "csrc" / f).write_text("v1 " + f)
     sha = bench.kernel_source_sha()
-    (tmp_path / "profiles" / "r04_traffic_c3.json").write_text(json.dumps(
+    (tmp_path / "profiles" / "r05_traffic_c3.json").write_text(json.dumps(
         {"kernel_src_sha": sha, "envs": 4096, "evs": 50, "config": "c3", "hbm_bytes_per_launch": 123.0}))
-    (tmp_path / "profiles" / "r04_traffic_16384x50.json").write_text(json.dumps(
+    (tmp_path / "profiles" / "r05_traffic_16384x50.json").write_text(json.dumps(
         {"kernel_src_sha": sha, "envs": 16384, "evs": 50, "config": "c3", "hbm_bytes_per_launch": 456.0}))
     val, src = bench.committed_traffic("c3", 4096, 50)
-    assert val == 123.0 and "profiles/r04_traffic_c3.json" in src  # the JSON line says where the figure comes from
+    assert val == 123.0 and "profiles/r05_traffic_c3.json" in src  # the JSON line says where the figure comes from
     assert bench.committed_traffic("c3", 16384, 50)[0] == 456.0  # an override's shape has a profile of its own
     assert bench.committed_traffic("c3", 8192, 50)[0] is None
     assert bench.committed_traffic("c5", 8192, 200)[0] is None

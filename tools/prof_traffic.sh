@@ -1,4 +1,4 @@
-# usage: bash tools/prof_traffic.sh <tag> [bench args...]   (on the GPU box through gpurun); tag = r04_traffic_<config>, the
+# usage: bash tools/prof_traffic.sh <tag> [bench args...]   (on the GPU box through gpurun); tag = r05_traffic_<config>, the
 # result (gpurun_out/prof/<tag>/traffic.json) is what gets committed as profiles/<tag>.json
 # HBM traffic of the step kernel from the L2's memory-side counters, collected as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), kernel-trace only.
