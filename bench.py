@@ -505,7 +505,7 @@ def host_path(g0, groups, budget_s: float = 1.0):
         t0 = time.perf_counter()
         n = 0
         while time.perf_counter() - t0 < budget_s:
-            g0.batch.step(acts[n % 8], copy=copy)
+            g0.batch.step(acts[n % len(acts)], copy=copy)
             n += 1
         dt = time.perf_counter() - t0
         return g0.E * n / dt, dt * 1e3 / n

@@ -12,11 +12,13 @@
 //                               utils/battery_degradation/*.py  (+ third-party rainflow.extract_cycles)
 //   FleetEnv.reset (incl. the vec-env auto-reset)  fleet_environment.py:330-434
 //
-// Mapping.  One *group* of G lanes owns one env (G = smallest power of two >= min(N,64)); a 64-lane wavefront
-// holds 64/G envs and a 256-thread workgroup 256/G.  Lane g of a group owns EVs g, g+G, ...  Per-env sums
-// (cashflow, reward, sum(action*there), penalty record) are reduced inside the wavefront -- lane-swap folds of four
-// quantities at once for one env per wavefront, DPP row shifts / row broadcasts otherwise -- no LDS round trip, no atomics.  Every lane of a group tracks the per-env scalars (time row,
-// episode end, sample count) redundantly in registers, so nothing written by one lane is re-read by another
+// Mapping.  One *group* of G lanes owns one env.  Up to 256 EVs per env every EV has a lane of its own: G = the smallest power
+// of two >= N up to 64 (a 64-lane wavefront holds 64/G envs, a 256-thread workgroup 256/G), and two or four whole wavefronts of
+// one workgroup for 64 < N <= 256 (kMaxGroup); beyond that lane g of a one-wavefront group walks EVs g, g+64, ...  Per-env sums
+// (cashflow, reward, sum(action*there), penalty record) are reduced inside the wavefront -- lane-swap folds of four quantities at
+// once for a whole wavefront, DPP row shifts / row broadcasts for smaller groups -- and, for an env of several wavefronts, the
+// per-wavefront partial sums meet in the LDS behind one workgroup barrier; no atomics.  Every lane of a group tracks the per-env
+// scalars (time row, episode end, sample count) redundantly in registers, so nothing written by one lane is re-read by another
 // inside a launch.  No MFMA: there is no contraction on this path.
 //
 // Schedule columns in run-length form.  What a step needs of the (time row, EV) table -- There, time_left, SOC_on_return of
