@@ -28,9 +28,10 @@ def test_hip_matches_reference_trace(name):
     frac = worst["obs_words_exact"] / max(worst["obs_words"], 1)
     print(name, worst, f"float32 observation words identical to the reference's: {100 * frac:.4f} %")
     assert worst["obs"] <= 1e-5 and worst["reward"] < 1e-9 and worst["soc"] < 1e-9 and worst["soh"] < 1e-9
-    # the auxiliary slots are computed per lane with a reciprocal instead of two divisions (fleet_kernels.hip write_obs_ev): a
-    # word may differ in its last bit when the float64 value sits on a float32 rounding boundary
-    assert frac >= 0.999, frac
+    # the auxiliary slots are computed per lane with a reciprocal instead of two divisions (fleet_kernels.hip write_obs_ev): they are
+    # tolerance-exact, not bit-exact -- a word may differ in its last bit when the float64 value sits on a float32 rounding boundary.
+    # Measured (profiles/r05_obs_words_identical.txt): 100 % on 15 of the 17 traces, 99.996 % and 99.985 % on the other two
+    assert frac >= 0.9998, frac
 
 
 @pytest.mark.parametrize("name", ["ct5_both_rainflow", "lmd5_price_linear"])

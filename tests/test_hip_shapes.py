@@ -84,7 +84,10 @@ def _compare(uc, n_evs, num_envs, deg, norm, steps, aux=True, building=True, pv=
     cpu.close()
 
 
-@pytest.mark.parametrize("n_evs,num_envs", [(1, 130), (2, 67), (3, 50), (7, 41), (16, 33), (31, 9), (64, 6), (70, 5), (200, 3)])
+# (N > 64: two wavefronts per env up to 128 EVs -- 100 with an odd number of envs: a partly filled last workgroup behind its barrier --,
+# four up to 256, and beyond that one wavefront whose lanes walk several EVs each)
+@pytest.mark.parametrize("n_evs,num_envs", [(1, 130), (2, 67), (3, 50), (7, 41), (16, 33), (31, 9), (64, 6), (70, 5), (100, 7), (128, 4),
+                                            (130, 5), (200, 3), (256, 3), (257, 2)])
 def test_group_geometries_rainflow(n_evs, num_envs):
     _compare("lmd", n_evs, num_envs, "rainflow", False, steps=200)
 
@@ -422,7 +425,7 @@ def test_seeded_random_configurations(case):
     cpu.close()
 
 
-@pytest.mark.parametrize("n_evs,num_envs", [(50, 70), (130, 21), (8, 45)])
+@pytest.mark.parametrize("n_evs,num_envs", [(50, 70), (130, 21), (100, 9), (8, 45)])
 def test_k_steps_per_launch_match_the_oracle_step_by_step(n_evs, num_envs):
     """`fleet_step_many_dev` at the geometries of the BASELINE shapes -- one env per wavefront with one EV per lane (N = 50: the
     kernel that carries the head of each EV's rainflow row in registers over the K steps), several EVs per lane (N = 130) and
