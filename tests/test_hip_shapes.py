@@ -363,14 +363,14 @@ def test_sharding_invariance_and_determinism():
         b.close()
 
 
-def _fuzz_cases(n, seed=2024):
+def _fuzz_cases(n, seed=2024, sizes=(1, 2, 3, 5, 9, 17, 33, 50, 65, 90)):
     """Seeded random corners of the supported matrix: fleet type x EVs per env x observer flags x
     normalisation x degradation model x episode length x real_time."""
     rng = np.random.default_rng(seed)
     cases = []
     while len(cases) < n:
         uc = ["lmd", "ct", "ut"][int(rng.integers(3))]
-        n_evs = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 50, 65, 90]))
+        n_evs = int(rng.choice(list(sizes)))
         building, pv = bool(rng.integers(2)), bool(rng.integers(2))
         norm = bool(rng.integers(2))
         if norm and pv and not building:
@@ -386,9 +386,11 @@ def _fuzz_cases(n, seed=2024):
     return cases
 
 
-@pytest.mark.parametrize("case", _fuzz_cases(24), ids=lambda c: "-".join(str(x) for x in c))
+@pytest.mark.parametrize("case", _fuzz_cases(24) + _fuzz_cases(10, seed=77, sizes=(100, 128, 130, 160, 200, 256)),
+                         ids=lambda c: "-".join(str(x) for x in c))
 def test_seeded_random_configurations(case):
-    """HIP against the oracle on 24 seeded random configurations, 130 steps each with auto-reset."""
+    """HIP against the oracle on 34 seeded random configurations (the last ten: envs of two / four wavefronts), 130 steps each with
+    auto-reset."""
     uc, n_evs, envs, deg, norm, aux, building, pv, ep, rt = case
     from fleetrl_amd.batch import FleetBatch
     from oracle.fleet_oracle import OracleBatch
