@@ -429,15 +429,23 @@ def main():
         g0 = max(groups, key=lambda g: g.E * g.N)
         per = g0.batch.time_steps_dev(min(args.steps, 512), g0.tape.data_ptr(), g0.L, g0.obs.data_ptr(), g0.reward.data_ptr(), g0.done.data_ptr())
         # K-steps-per-launch entry (open-loop rollouts), reported aside
-        K = min(64, L)
+        # (an open-loop rollout of K steps consumes K steps of actions: a tape of its own where the single-step tape is shorter)
+        K = min(64, max(args.steps, 1))
+        ktape = g0.tape
+        if g0.L < K:
+            gen = torch.Generator(device=dev).manual_seed(7)
+            ktape = torch.rand((K, g0.E, g0.N), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+            ktape[torch.rand((K, g0.E, g0.N), device=dev, generator=gen) < 0.15] = 0.0
+            torch.cuda.synchronize()
         rsum = torch.empty(g0.E, device=dev, dtype=torch.float64)
-        g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
+        g0.batch.step_many_dev(K, ktape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
         g0.batch.synchronize()
         g0.batch.timer_start()
         many_reps = max(1, min(args.steps, 2048) // K)
         for _ in range(many_reps):
-            g0.batch.step_many_dev(K, g0.tape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
+            g0.batch.step_many_dev(K, ktape.data_ptr(), g0.obs.data_ptr(), rsum.data_ptr())
         many_ms = g0.batch.timer_stop()
+        del ktape
         if check:
             g0.batch.check_errors()
         fleets = "+".join(g.use_case for g in groups)

@@ -119,7 +119,7 @@ __device__ __forceinline__ double dpp_add(double v) {
 template <int G>
 __device__ __forceinline__ bool group_any(bool v) {
   const unsigned long long m = __ballot(v);
-  if (G >= 64) return m != 0ull;  // (groups of several wavefronts exist in the single-step kernel only: no event test there)
+  if (G >= 64) return m != 0ull;  // (groups of several wavefronts never run the event-skipping loop: launch_step_gd)
   const int base = (int)(threadIdx.x % 64) & ~(G - 1);
   return ((m >> base) & ((1ull << (G % 64)) - 1ull)) != 0ull;
 }
@@ -1270,25 +1270,28 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       wave_sum4_to_last(cash, rew, asum, penrec);  // this wavefront's lanes: totals in its last lane
       if (G > 64) {
         // an env of several wavefronts: their partial sums meet in the LDS and the group's last lane adds them in wavefront order
-        static_assert(G <= 64 || !MULTI, "wavefronts of a K-step launch advance independently: no workgroup barrier inside the step");
-        __shared__ double s_part[kBlock / 64][4];
+        // (K steps per launch: the env's wavefronts meet here once per step -- every wavefront of the workgroup runs the same K
+        // steps, so the barrier is uniform; two buffers in turn, so that a wavefront already in the next step does not overwrite
+        // what the leader is still adding up.  The event-skipping loop of real_time has env-dependent trip counts: never here.)
+        __shared__ double s_part[2][kBlock / 64][4];
+        double(*part)[4] = s_part[MULTI ? (k & 1) : 0];
         const int w = (int)threadIdx.x / 64;
         if ((threadIdx.x & 63) == 63) {
-          s_part[w][0] = cash;
-          s_part[w][1] = rew;
-          s_part[w][2] = asum;
-          s_part[w][3] = penrec;
+          part[w][0] = cash;
+          part[w][1] = rew;
+          part[w][2] = asum;
+          part[w][3] = penrec;
         }
         __syncthreads();
         if (leader) {
           const int w0 = ((int)threadIdx.x / G) * (G / 64);
           double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-          for (int k = 0; k < G / 64; ++k) {
-            s0 += s_part[w0 + k][0];
-            s1 += s_part[w0 + k][1];
-            s2 += s_part[w0 + k][2];
-            s3 += s_part[w0 + k][3];
+          for (int j = 0; j < G / 64; ++j) {
+            s0 += part[w0 + j][0];
+            s1 += part[w0 + j][1];
+            s2 += part[w0 + j][2];
+            s3 += part[w0 + j][3];
           }
           cash = s0;
           rew = s1;
@@ -1584,8 +1587,19 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
-  if (G == 64 && single && d.N > 64 && d.N <= kMaxGroup) {  // one EV per lane, two or four wavefronts per env
+  // K steps per launch from a tape or a built-in policy keep one EV per lane too (not the event-skipping loop, not the data log)
+  const bool many_grouped = (!single && !d.real_time && !d.log_pos);
+  if (G == 64 && (single || many_grouped) && d.N > 64 && d.N <= kMaxGroup) {  // one EV per lane, two or four wavefronts per env
     constexpr int GG2 = (G == 64) ? 128 : G, GG4 = (G == 64) ? 256 : G;  // (only instantiated behind G == 64)
+    if (many_grouped) {
+      if (d.N <= 128)
+        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, true, false>), dim3((d.E + 1) / 2), block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs,
+                           reward, done, terminal_obs, done_count);
+      else
+        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, true, false>), dim3(d.E), block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
+                           terminal_obs, done_count);
+      return hipGetLastError();
+    }
     if (d.N <= 128) {
       const dim3 g2((d.E + 1) / 2);
       if (f64 == FLEET_ACT_F64)
