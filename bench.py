@@ -320,9 +320,9 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if launched:
+        if launched:  # one rank: the synchronize IS the barrier (a second one would only add host time to every timed region)
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ---- the timed regions: each is exactly K steps between two barriers ------------------------------------------------------
     # One region is what the contract describes (barrier + synchronize, K launches, synchronize + barrier).  A single region of
