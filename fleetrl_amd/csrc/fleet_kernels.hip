@@ -468,6 +468,11 @@ __device__ __forceinline__ void rf_begin(const FleetDev& d, const EvIx& i, doubl
 }
 // `top`: the stack top after the push (only written when a point was pushed)
 // `acc_out`: the accumulator head after the push (only written when the push closed a cycle)
+// Shape (round 5): the push that closes nothing, the half cycle and the FIRST full cycle are one straight line of selects -- the
+// only memory they need is what rf_request brought (top two entries, the two below, the accumulators) -- and only a second closure
+// of the same push (the new top against what lies below: rare) enters a loop that reads stack words.  The general loop of rounds
+// 2-4 walked every push through its loop control and the first-point test: 8.3 -> 7.9 us per 4096x50 launch for the same
+// algorithm (profiles/r05_experiments/ab7_rf_finish_peeled.log).
 __device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, const RfReq& q, int& tail, RfTop& top, RfAccHead& acc_out,
                                           uint32_t& err) {
   if (!q.push) return;
@@ -478,60 +483,66 @@ __device__ __forceinline__ void rf_finish(const FleetDev& d, const EvIx& i, cons
     return;
   }
   const double p = q.p;
-  double a = q.top.s1, b = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
-  const bool closes = (tail + 1 >= 3) && !(fabs(p - b) < fabs(b - a));
-  if (!closes) {
-    st_plain(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + tail - 1)), b);  // the displaced top joins the stack words; tail >= 1
-    tail += 1;
-    top.s1 = b;
-    top.s2 = p;
-    st_plain(reinterpret_cast<RfTop*>(row + 2), top);
-    return;
-  }
-  int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;  // entries below the top two that are in registers
-  const double w0 = q.w0, w1 = q.w1;
-  tail += 1;
+  const double a0 = q.top.s1, b0 = q.top.s2;  // stack[tail-2] (also in the stack words), stack[tail-1] (only in the header)
+  const int size = tail + 1;                  // points on the stack with p pushed
+  const bool closes = (size >= 3) && !(fabs(p - b0) < fabs(b0 - a0));
+  const bool half = closes && (size == 3);    // Y contains the starting point: half cycle, the first point is dropped
+  // ONE store for b0: it joins the stack words when nothing closes (slot tail-1) and is rewritten to slot 0 when the first point
+  // is dropped; a full cycle leaves the stack words as they are
+  if (!closes || half) st_plain(rf_row_of(d, i, (unsigned)(RF_HDR_WORDS + (half ? 0 : tail - 1))), b0);
   const int L = q.acc.rf_len;
   int nc = q.acc.nc;
   double mean_sum = q.acc.mean_sum, dcsum = 0.0;
   bool has_csum = false;
-  while (tail >= 3) {
-    const double X = fabs(p - b), Y = fabs(b - a);
-    if (X < Y) break;
+  double a = a0, b = b0;
+  int t = size;
+  if (closes) {
     if (nc >= L - 1) {  // only the closed cycles beyond the last evaluation's count carry stress: none in the steady state
-      dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (tail == 3) ? 0.5 : 1.0, d.self->stress_temp);
+      dcsum = cycle_stress(fabs(a0 - b0), 0.5 * (a0 + b0), half ? 0.5 : 1.0, d.self->stress_temp);
       has_csum = true;
     }
-    mean_sum += 0.5 * (a + b);
+    mean_sum += 0.5 * (a0 + b0);
     nc += 1;
-    if (tail == 3) {  // Y contains the starting point: half cycle, drop the first point -> stack = [b, p]
-      stk[0] = b;
-      tail = 2;
-    } else {  // full cycle, drop its two points -> stack = [..., p]: the stack words keep what they have, p lives in s2
-      tail -= 2;
-      if (nwin >= 1) b = w0;                       // stack[tail-2]; tail >= 2 here
-      else b = stk[tail - 2];
-      if (tail >= 3) {
-        if (nwin >= 2) a = w1;                     // stack[tail-3]
-        else a = stk[tail - 3];
-      } else {
-        a = 0.0;
+    if (half) {
+      t = 2;  // stack = [b0, p]
+    } else {  // full cycle: its two points vanish, p lives in s2, the entries below come from the request
+      t = size - 2;
+      const int nwin = q.win ? (tail - 2 > 2 ? 2 : tail - 2) : 0;
+      b = (nwin >= 1) ? q.w0 : stk[t - 2];
+      a = (t >= 3) ? ((nwin >= 2) ? q.w1 : stk[t - 3]) : 0.0;
+      while (t >= 3) {  // further closures of the new top against what lies below: rare, from the stack words
+        if (fabs(p - b) < fabs(b - a)) break;
+        if (nc >= L - 1) {
+          dcsum += cycle_stress(fabs(a - b), 0.5 * (a + b), (t == 3) ? 0.5 : 1.0, d.self->stress_temp);
+          has_csum = true;
+        }
+        mean_sum += 0.5 * (a + b);
+        nc += 1;
+        if (t == 3) {
+          stk[0] = b;
+          t = 2;
+        } else {
+          t -= 2;
+          b = stk[t - 2];
+          a = (t >= 3) ? stk[t - 3] : 0.0;
+        }
       }
-      nwin = 0;
     }
   }
-  RfAccHead out;
-  out.mean_sum = mean_sum;
-  out.nc = nc;
-  out.rf_len = L;
+  tail = t;
   top.s1 = b;  // stack[tail-2]
   top.s2 = p;  // stack[tail-1]
-  acc_out = out;
-  st_plain(reinterpret_cast<RfAccHead*>(row), out);
   st_plain(reinterpret_cast<RfTop*>(row + 2), top);
-  if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
+  if (closes) {
+    RfAccHead out;
+    out.mean_sum = mean_sum;
+    out.nc = nc;
+    out.rf_len = L;
+    acc_out = out;
+    st_plain(reinterpret_cast<RfAccHead*>(row), out);
+    if (has_csum) reinterpret_cast<RfHdr*>(row)->csum += dcsum;
+  }
 }
-
 // RainflowSeiDegradation.calculate_degradation for one EV on the daily row (rainflow_sei_degradation.py:91-212).
 // `v` = the sample just logged (forced last reversal), `n` = number of logged samples.  The forced point and the
 // residual half cycles are evaluated on a virtual stack (vt, vh, registers a/b); nothing of the streaming state
