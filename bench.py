@@ -357,6 +357,12 @@ def main():
     order = sorted(range(reps), key=lambda i: walls[i])
     wall = walls[order[reps // 2]]
     ev_ms = sorted(ev_regions, key=max)[len(ev_regions) // 2]
+    # every rank's own kernel time per step (N > 1: the line reports rank 0's roofline; the spread over the ranks beside it)
+    k_rank = torch.tensor([max(ev_ms) / args.steps], device=cdev, dtype=torch.float64)
+    k_all = [k_rank.clone() for _ in range(world)] if launched else [k_rank]
+    if launched:
+        dist.all_gather(k_all, k_rank)
+    k_ranks = [float(x.item()) for x in k_all]
     # ---- logging collective: one all-gather of finished-episode returns / lengths (RCCL over xGMI when N > 1) ------------------
     t1 = time.perf_counter()
     off = 0
@@ -468,7 +474,9 @@ def main():
             "config": {"workload": f"{E} envs x {N} EVs per GPU, {fleets} fleet{'s (one third each)' if len(groups) > 1 else ''}, "
                                    f"{'load+pv' if spec['building'] and spec['pv'] else 'price-only'} obs, {spec['deg']} degradation, "
                                    f"{'spot_2021-like prices + fixed feed-in tariff, ' if spec['price_year'] == '2021' else ''}"
-                                   f"48 h episodes, random start rows, auto-reset ({spec['what']})",
+                                   f"48 h episodes, random start rows, auto-reset ({spec['what']})"
+                                   + ("; NOTE: 2048 envs per GPU are two wavefronts per SIMD -- the launch is latency-bound (0.17 of the "
+                                      "roof), a multi-GPU run of this config scales while every GPU idles" if args.config == "c4" else ""),
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
                        "launch": (f"hipGraph of {graph_len} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
@@ -477,6 +485,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name(N, spec["deg"]), "kernel_ms": k_ms,
+                         "kernel_ms_ranks_min": min(k_ranks), "kernel_ms_ranks_max": max(k_ranks),
                          "kernel_src_sha": kernel_source_sha(),
                          "algorithmic_bytes_per_env_step": bytes_launch / E, "bytes_per_launch": bytes_launch,
                          "kernel_ms_event_pair_per_launch": float(np.mean(per))},
