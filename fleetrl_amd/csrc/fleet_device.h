@@ -55,13 +55,11 @@ struct SegRec {
 #define SEG_THERE(se) ((se) >> 31)
 // db["time_left"] of row r from the record of r's segment (exact float32: checked row by row when the table was built)
 __host__ __device__ inline float seg_tl(const SegRec& s, int r, double dt) {
-  if (s.se & SEG_RAW) {
-    union { uint32_t u; float f; } v;
-    v.u = s.tlx;
-    return v.f;
-  }
+  union { uint32_t u; float f; } v;
+  v.u = s.tlx;
   const int left = (int)s.tlx - r;
-  return left > 0 ? (float)((double)left * dt) : 0.0f;
+  const float reg = left > 0 ? (float)((double)left * dt) : 0.0f;
+  return (s.se & SEG_RAW) ? v.f : reg;  // (a select: the RAW case is a table property, the lanes of a wavefront may differ)
 }
 
 #define FLEET_TFLAG_DEG 1u    // hour == 14 && minute == 45   (fleet_environment.py:665)

@@ -873,7 +873,10 @@ __device__ __forceinline__ EvPhys ev_physics(const FleetDev& d, const Hot& hb, d
   const double left = -1.0 * soc * cap;      // ev_total_energy_left :161
   // overcharging / over-discharging penalty :104-107 (applied even to an absent EV, clipped; quirk Q9) and
   // :165-167 (needs presence, not clipped)
-  const bool viol = pos ? (dem * d.eta_c > need) : ((dem * d.eta_d < left) && (th != 0u));
+  // (both products computed: a short-circuit would cost two masked regions for one multiplication)
+  const bool viol_c = dem * d.eta_c > need;
+  const bool viol_d = (dem * d.eta_d < left) & (th != 0u);
+  const bool viol = pos ? viol_c : viol_d;
   const double x = pos ? (dem - need) : (left - dem);
   const double pen_raw = d.penalty_oc * (x * x);
   const double pen_oc = pos ? fmax(pen_raw, d.clip_oc) : pen_raw;
