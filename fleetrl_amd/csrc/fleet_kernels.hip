@@ -847,9 +847,9 @@ struct EvPhys {
   double a_th;          // action * there (fleet_environment.py:491)
   float hl;             // episode.hours_left
   bool pos, t090;       // action >= 0; sticky "target_soc = 0.9" (quirk Q7)
-  bool event;           // MULTI: something the reference counts into episode.events (real_time)
+  bool event;           // EVENTS: something the reference counts into episode.events (real_time)
 };
-template <bool MULTI>
+template <bool EVENTS>
 __device__ __forceinline__ EvPhys ev_physics(const FleetDev& d, const Hot& hb, double old_deg, const RowRec& tb1, double soh0, double a,
                                              double dt_step, bool lunch) {
   EvPhys o;
@@ -885,14 +885,14 @@ __device__ __forceinline__ EvPhys ev_physics(const FleetDev& d, const Hot& hb, d
   const double en_p = pos ? fmin(lim, dem) : fmax(left, dem);  // :114 / :174
   const double en = present ? en_p : 0.0;
   rew += (!present && fabs(a) > 0.05) ? d.penalty_invalid * (a * a) : 0.0;  // :120-122 / :180-182
-  if (MULTI) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);      // episode.events :108,123,168,183
+  if (EVENTS) ev_lane = ev_lane || viol || (!present && fabs(a) > 0.05);     // episode.events :108,123,168,183
   soc = soc + div_rcp(pos ? en * d.eta_c : en, cap, rcp_newton1(cap));  // soc + energy / cap, the quotient correctly rounded :128 / :189
   o.a_th = a * (double)th;  // corrected_actions = actions * there (fleet_environment.py:491)
 
   // ---- arrival / departure state machine (fleet_environment.py:528-623) ----------------------------------
   const float ntl = tb1.tl;
   // departure :532, arrival :603, low state of health :615 are events too
-  if (MULTI) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (soh0 <= 0.9);
+  if (EVENTS) ev_lane = ev_lane || ((hl != 0.0f) != (ntl != 0.0f)) || (soh0 <= 0.9);
   if ((hl != 0.0f) && (ntl == 0.0f)) {  // a car just left :531
     const double target = lunch ? d.target_soc_lunch : tgt;  // :536-557
     const double missing = target - soc;
@@ -945,7 +945,13 @@ struct StepKernargPrefix {
 };
 static_assert(offsetof(StepKernargPrefix, d_arg) == 48 && alignof(FleetDev) == 8, "twelve preloaded dwords, then the argument block");
 
-template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false>
+// What a K-step instance carries besides the action tape (MULTI only; round 5): the built-in policies and the event-skipping loop of
+// real_time each cost the tape rollout scalar registers it spills and branches it never takes -- compiled per use, the tape-only
+// instance runs 9 % faster (9.35e8 -> 1.02e9 env-steps/s at 4096x50, profiles/r05_experiments/ab11_kstep_kernel_per_mode.log).
+// kModeAll = everything behind run-time tests (the data-log instances and the small groups, where instances are not multiplied).
+constexpr int kModeAll = 0, kModeTape = 1, kModePolicy = 2, kModeRt = 3;
+
+template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false, int MODE = kModeAll>
 __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
@@ -977,6 +983,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       return d_arg;
     }
   };
+  constexpr bool kPol = MULTI && (MODE == kModeAll || MODE == kModePolicy);  // the built-in policies are compiled in
+  constexpr bool kRt = MULTI && (MODE == kModeAll || MODE == kModeRt);       // the event-skipping loop is compiled in
   const int N = p_N, E_ = p_E;
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
   // night-charging policy: the env's "charging since" row travels in a register over the K steps
   int night_st = FLEET_NIGHT_IDLE;
-  if (MULTI && act_mode == FLEET_ACT_POLICY_NIGHT) {
+  if (kPol && act_mode == FLEET_ACT_POLICY_NIGHT) {
     night_st = d.cold->night_start[e];
     if (G >= 64) night_st = __builtin_amdgcn_readfirstlane(night_st);
   }
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
   // real_time (event-skipping, fleet_environment.py:453,692-699): the launch repeats the step with the same action until
   // a relevant event happened; it reports the LAST pass's observation / reward / done.  Multi-step kernel, K == 1.
-  const bool rt = MULTI && (d.real_time != 0);
+  const bool rt = kRt && (d.real_time != 0);
   // K steps per launch, one EV per lane: the head of the EV's rainflow row (closed-cycle count, sum of means, rainflow_length,
   // the two newest stack entries) is read ONCE per launch and carried in registers over the K steps -- a push updates the
   // registers and stores to the row, nothing re-reads it; the stack words are only read when a closure pops into them
@@ -1124,7 +1132,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // Which action rule applies to this env in this step (policies only; FLEET_ACT_POLICY_NIGHT resolves to one of
     // "all zeros" / "all ones" / the distributed rule per step, benchmarking/night_charging.py:81-98)
     int pol = act_mode;
-    if (MULTI && act_mode == FLEET_ACT_POLICY_NIGHT) {
+    if (kPol && act_mode == FLEET_ACT_POLICY_NIGHT) {
       const FleetCold* cd = d.cold;
       const int hm = cd->tab_hm[t];
       const int hour = hm >> 8, minute = hm & 255;
@@ -1195,7 +1203,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
         rf_request(d, i, HOT_TAIL(hb.bits), rq);
       }
       double a;
-      if (MULTI && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
+      if (kPol && act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) {
         // built-in open-loop policies of the reference's benchmark harnesses, evaluated in place of an action tape
         if (pol == FLEET_ACT_POLICY_UNCONTROLLED) {
           a = 1.0;  // benchmarking/uncontrolled_charging.py:51-54: np.ones(n_evs)
@@ -1231,7 +1239,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (crosses) nr = *ev_at(d.seg, it2);
       const RowRec tb1 = seg_row(rr, t1, d.dt);
       FLEET_STAMP(2);
-      const EvPhys ph_ev = ev_physics<MULTI>(d, hb, old_deg, tb1, soh0, a, dt_step, lunch);
+      const EvPhys ph_ev = ev_physics<kRt>(d, hb, old_deg, tb1, soh0, a, dt_step, lunch);
       double soc = ph_ev.soc;
       float hl = ph_ev.hl;
       const bool t090 = ph_ev.t090, pos = ph_ev.pos;
@@ -1240,7 +1248,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       penrec += ph_ev.penrec;
       miss_sum += ph_ev.miss;
       asum += ph_ev.a_th;
-      if (MULTI) ev_lane = ev_lane || ph_ev.event;
+      if (kRt) ev_lane = ev_lane || ph_ev.event;
       // ---- SOC log (:655): the new sample of the streaming rainflow; what a cycle closure needs of the EV's row is requested
       // here and consumed after the observation stores and the money terms
       int tail = HOT_TAIL(hb.bits), sgn = HOT_SGN(hb.bits);
@@ -1330,7 +1338,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
         const double pen = overloading_penalty(over / d.grid_connection + 1.0, d.penalty_overload);
         rew += pen;
         penalty_record += pen;
-        if (MULTI) ev_lane = true;  // :499
+        if (kRt) ev_lane = true;  // :499
       }
       if (logs) {
         d.log_row[lrow] = t1;  // episode.time
@@ -1441,7 +1449,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       reward[e] = rt ? last_rew : reward_sum;
       if (done && (rt || steps == 1)) done[e] = (rt ? last_done : (n_done != 0)) ? 1 : 0;  // one agent step: its done flag
       if (done_count) done_count[e] = n_done;
-      if (act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
+      if (kPol && act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
   }
   if (err && env_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
@@ -1592,13 +1600,28 @@ int group_size(int N) {
   return G;
 }
 
+// A K-step launch without the data log: the instance that carries what the launch uses -- the tape only, the built-in policies, or the
+// event-skipping loop (groups of 32 lanes and more; smaller groups keep ONE instance with everything behind run-time tests).
+template <int G, int DEG, bool WIDE>
+void launch_many(const FleetDev& d, dim3 grid, dim3 block, const void* actions, int act_mode, int K, float* obs, double* reward,
+                 uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
+#define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
+#define FLEET_MANY(MODE)                                                                                                          \
+  hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, WIDE, false, false, MODE>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, act_mode, K, \
+                     obs, reward, done, terminal_obs, done_count)
+  if (G < 32) FLEET_MANY(kModeAll);
+  else if (d.real_time) FLEET_MANY((G < 32 ? kModeAll : kModeRt));
+  else if (act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) FLEET_MANY((G < 32 ? kModeAll : kModePolicy));
+  else FLEET_MANY((G < 32 ? kModeAll : kModeTape));
+#undef FLEET_MANY
+}
+
 template <int G, int DEG>
 hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
   const int epb = kBlock / G;
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
-#define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
   // K steps per launch from a tape or a built-in policy keep one EV per lane too (not the event-skipping loop, not the data log)
@@ -1606,12 +1629,8 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   if (G == 64 && (single || many_grouped) && d.N > 64 && d.N <= kMaxGroup) {  // one EV per lane, two or four wavefronts per env
     constexpr int GG2 = (G == 64) ? 128 : G, GG4 = (G == 64) ? 256 : G;  // (only instantiated behind G == 64)
     if (many_grouped) {
-      if (d.N <= 128)
-        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, true, false>), dim3((d.E + 1) / 2), block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs,
-                           reward, done, terminal_obs, done_count);
-      else
-        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, true, false>), dim3(d.E), block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
-                           terminal_obs, done_count);
+      if (d.N <= 128) launch_many<GG2, DEG, false>(d, dim3((d.E + 1) / 2), block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
+      else launch_many<GG4, DEG, false>(d, dim3(d.E), block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
       return hipGetLastError();
     }
     if (d.N <= 128) {
@@ -1641,8 +1660,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64), true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
     else
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
-                         done, terminal_obs, done_count);
+      launch_many<G, DEG, (G == 64)>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   } else {
     if (single && f64 == FLEET_ACT_F64)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
@@ -1654,8 +1672,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
                          terminal_obs, done_count);
     else
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
-                         terminal_obs, done_count);
+      launch_many<G, DEG, false>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   }
   return hipGetLastError();
 }
