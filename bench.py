@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
     ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--launch", choices=("graph", "eager", "direct"), default="graph",
+                    help="how the K launches of a region reach the GPU: a replayed hipGraph (eager below 64 steps), one hipLaunchKernel "
+                         "each, or AQL packets written by the library into a queue of its own without the L2 write-back HIP attaches "
+                         "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--tape-len", type=int, default=None,
@@ -288,7 +292,9 @@ def main():
     graph_len = L * ((64 + L - 1) // L)  # launches per captured graph: whole tape cycles, at least 64 (fleet_run_tape_dev)
     # launches go through a captured hipGraph of L steps; a run shorter than 64 steps launches eagerly (one graph launch costs
     # about as much as six kernel launches on the host: 9.9 vs 9.65 us per step measured for the driver's 20-step regions)
-    use_graph = (not args.no_graph) and args.steps >= 64
+    use_graph = int((not args.no_graph) and args.launch == "graph" and args.steps >= 64)
+    if args.launch == "direct":
+        use_graph = 2  # _capi.LAUNCH_DIRECT
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):
         lo, hi = shard_range(E, len(spec["groups"]), k)  # env groups in order: the first E % n groups hold one env more
@@ -457,7 +463,9 @@ def main():
         fleets = "+".join(g.use_case for g in groups)
         traffic, traffic_source = (committed_traffic(args.config, E, N) if not (args.deg or args.use_case)
                                    else (None, "diagnostic override of the workload"))
-        graph_used = use_graph and args.steps >= graph_len
+        graph_used = use_graph == 1 and args.steps >= graph_len
+        launch_desc = (f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph != 2 else \
+            "AQL packets written by the library (own HSA queue): agent-scope acquire on every launch, L2 write-back only after the last of the region"
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -479,7 +487,7 @@ def main():
                                       "roof), a multi-GPU run of this config scales while every GPU idles" if args.config == "c4" else ""),
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
-                       "launch": (f"hipGraph of {graph_len} launches" if graph_used else "eager"), "prime_ms": args.prime_ms,
+                       "launch": launch_desc, "prime_ms": args.prime_ms,
                        "action_tape": f"{L} steps x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

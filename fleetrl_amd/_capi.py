@@ -17,6 +17,8 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
 PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
+# fleet_run_tape_dev / fleet_time_regions_begin: how the launches reach the GPU (include/fleet_hip.h FLEET_LAUNCH_*)
+LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT = 0, 1, 2
 POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
 DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL = 1, 2, 4, 8, 16, 32

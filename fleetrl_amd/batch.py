@@ -298,7 +298,7 @@ class FleetBatch:
     def run_tape_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
                      use_graph: bool = True, act_dtype: int = _capi.ACT_F32):
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
-                                                 reward_ptr, done_ptr, int(bool(use_graph))))
+                                                 reward_ptr, done_ptr, int(use_graph)))
 
     def time_steps_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
                        act_dtype: int = _capi.ACT_F32) -> np.ndarray:
@@ -313,7 +313,7 @@ class FleetBatch:
         """Enqueue `regions` event-bracketed regions of exactly `steps` launches each (asynchronous)."""
         self._n_regions = int(regions)
         self._check(self.lib.fleet_time_regions_begin(self.h, int(regions), int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
-                                                       reward_ptr, done_ptr, int(bool(use_graph))))
+                                                       reward_ptr, done_ptr, int(use_graph)))
 
     def time_regions_read(self) -> np.ndarray:
         """Per-region device durations [ms] of the regions enqueued by time_regions_begin."""

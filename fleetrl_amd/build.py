@@ -6,8 +6,8 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ("fleet_kernels.hip", "fleet_capi.hip")
-HEADERS = ("fleet_device.h", os.path.join("..", "..", "include", "fleet_hip.h"))  # relative to csrc/
+SOURCES = ("fleet_kernels.hip", "fleet_capi.hip", "fleet_direct.hip")
+HEADERS = ("fleet_device.h", "fleet_direct.h", os.path.join("..", "..", "include", "fleet_hip.h"))  # relative to csrc/
 # -ffp-contract=off: no fused multiply-add contraction, so float64 results follow the reference's operation
 # order bit for bit on the SOC path.  No -ffast-math for the same reason.
 # -mllvm -disable-machine-licm: the machine-level loop-invariant code motion hoists every rare path's constant
@@ -20,8 +20,33 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-mllvm", "-amdgpu-kernarg-preload-count=12", "-shared"]
 
 
+# the library also talks to the HSA runtime directly (fleet_direct.hip: AQL packets of its own for runs of steps)
+LINK = ["-L/opt/rocm/lib", "-lhsa-runtime64"]
+# ... and for that the step kernels once more as a plain code object, loaded through HSA: same source, same device flags
+GENCO = ["--genco", "--no-gpu-bundle-output"] + [f for f in FLAGS if f not in ("-fPIC", "-shared")]
+
+
 def lib_path() -> str:
     return os.path.join(_HERE, "libfleet_hip.so")
+
+
+def code_object_path(lib: str | None = None) -> str:
+    """The step kernels' code object that belongs to a library: <library without .so>.gfx950.hsaco (fleet_direct.hip looks there)."""
+    lib = lib or lib_path()
+    return (lib[:-3] if lib.endswith(".so") else lib) + ".gfx950.hsaco"
+
+
+def _compile(out_so: str, out_co: str, extra_flags=()) -> list:
+    """Both artefacts, side by side (two hipcc processes); returns the command lines.  Raises with the compiler's message."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmds = [[hipcc(), *FLAGS, *extra_flags, *[os.path.join(csrc, s) for s in SOURCES], *LINK, "-o", out_so],
+            [hipcc(), *GENCO, *extra_flags, os.path.join(csrc, "fleet_kernels.hip"), "-o", out_co]]
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for c in cmds]
+    outs = [p.communicate() for p in procs]
+    for p, (_, err) in zip(procs, outs):
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + err[-4000:])
+    return cmds
 
 
 def hipcc() -> str:
@@ -32,11 +57,11 @@ def hipcc() -> str:
 
 
 def needs_build() -> bool:
-    out = lib_path()
-    if not os.path.isfile(out):
-        return True
-    deps = [os.path.join(_HERE, "csrc", f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+    deps = [os.path.join(_HERE, "csrc", f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    for out in (lib_path(), code_object_path()):
+        if not os.path.isfile(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            return True
+    return False
 
 
 def build_variant(out: str, extra_flags) -> str:
@@ -45,11 +70,7 @@ def build_variant(out: str, extra_flags) -> str:
     out = os.path.abspath(out)
     if out == os.path.abspath(lib_path()):
         raise ValueError("a variant build must not overwrite the product library " + lib_path())
-    csrc = os.path.join(_HERE, "csrc")
-    cmd = [hipcc(), *FLAGS, *list(extra_flags), *[os.path.join(csrc, s) for s in SOURCES], "-o", out]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+    _compile(out, code_object_path(out), list(extra_flags))
     return out
 
 
@@ -67,23 +88,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
                            "only; use fleetrl_amd.build.build_variant(out, flags) for a diagnostic build under another file name")
     if not force and not needs_build():
         return lib_path()
-    csrc = os.path.join(_HERE, "csrc")
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not needs_build():  # another process built it while this one waited
                 return lib_path()
-            fd, tmp = tempfile.mkstemp(prefix=".libfleet_hip.", suffix=".so.tmp", dir=_HERE)
-            os.close(fd)
-            cmd = [hipcc(), *FLAGS, *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
-            res = subprocess.run(cmd, capture_output=True, text=True)
-            if res.returncode != 0:
-                os.unlink(tmp)
-                raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
-            os.chmod(tmp, 0o755)
-            os.replace(tmp, lib_path())
+            tmps = []
+            for suffix in (".so.tmp", ".hsaco.tmp"):
+                fd, tmp = tempfile.mkstemp(prefix=".libfleet_hip.", suffix=suffix, dir=_HERE)
+                os.close(fd)
+                tmps.append(tmp)
+            try:
+                cmds = _compile(tmps[0], tmps[1])
+            except Exception:
+                for t in tmps:
+                    if os.path.exists(t):
+                        os.unlink(t)
+                raise
+            os.chmod(tmps[0], 0o755)
+            os.replace(tmps[1], code_object_path())  # the code object first: a library never meets an older one
+            os.replace(tmps[0], lib_path())
             if verbose:
-                print(" ".join(cmd))
+                for c in cmds:
+                    print(" ".join(c))
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return lib_path()

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "fleet_device.h"
+#include "fleet_direct.h"
 
 namespace {
 
@@ -123,7 +124,28 @@ struct Batch {
   float* graph_obs = nullptr;
   double* graph_reward = nullptr;
   uint8_t* graph_done = nullptr;
+  // direct AQL submission of tape runs (fleet_direct.hip; FLEET_LAUNCH_DIRECT): the handle's own HSA queue, what its prepared
+  // argument blocks describe, the spans of the timed runs waited for so far
+  FleetDirect* direct = nullptr;
+  const void* dq_tape = nullptr;
+  int dq_len = 0, dq_dtype = 0;
+  float* dq_obs = nullptr;
+  double* dq_reward = nullptr;
+  uint8_t* dq_done = nullptr;
+  bool dq_timed = false;
+  std::vector<double> dq_spans_us;
 };
+
+// A run submitted to the handle's own queue is not on its HIP stream: every entry point that touches the handle waits for it first.
+static int direct_drain(Batch* h) {
+  if (!h || !h->direct) return FLEET_OK;
+  return fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error);
+}
+#define FLEET_ENTER(h)                          \
+  do {                                          \
+    const int _rc = direct_drain(h);            \
+    if (_rc != FLEET_OK) return _rc;            \
+  } while (0)
 
 #define HIP_TRY(b, expr)                                                                         \
   do {                                                                                           \
@@ -648,6 +670,8 @@ int fleet_create(const FleetParams* p, const FleetTables* t, int device, fleet_h
 int fleet_destroy(fleet_handle h) {
   if (!h) return FLEET_OK;
   (void)hipSetDevice(h->device);
+  if (h->direct) fleet_direct_close(h->direct);  // waits for a run in flight
+  h->direct = nullptr;
   (void)hipStreamSynchronize(h->stream);
   drop_graph(h);
   for (void* ptr : h->allocs) (void)hipFree(ptr);
@@ -668,6 +692,7 @@ int fleet_destroy(fleet_handle h) {
 const char* fleet_last_error(fleet_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 int fleet_set_stream(fleet_handle h, void* hip_stream) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // what was enqueued on the stream in use so far is finished before the switch
@@ -679,6 +704,7 @@ int fleet_set_stream(fleet_handle h, void* hip_stream) {
 }
 
 int fleet_use_own_stream(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -688,6 +714,7 @@ int fleet_use_own_stream(fleet_handle h) {
 }
 
 int fleet_synchronize(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return FLEET_OK;
@@ -695,6 +722,7 @@ int fleet_synchronize(fleet_handle h) {
 
 int fleet_stream_query(fleet_handle h) {
   if (!h) return FLEET_ERR_INVALID;
+  if (h->direct && fleet_direct_busy(h->direct)) return -1;
   const hipError_t e = hipStreamQuery(h->stream);
   if (e == hipSuccess) return FLEET_OK;
   if (e == hipErrorNotReady) {
@@ -706,6 +734,7 @@ int fleet_stream_query(fleet_handle h) {
 }
 
 int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episodes) {
+  FLEET_ENTER(h);
   if (!h || n_episodes < 0 || (n_episodes > 0 && !starts)) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -733,6 +762,7 @@ int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episod
 }
 
 int fleet_reset_dev(fleet_handle h, const uint8_t* mask, float* obs) {
+  FLEET_ENTER(h);
   if (!h || !obs) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, fleet_launch_reset(h->d, mask, obs, h->stream));
@@ -741,6 +771,7 @@ int fleet_reset_dev(fleet_handle h, const uint8_t* mask, float* obs) {
 
 int fleet_step_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
                    float* terminal_obs) {
+  FLEET_ENTER(h);
   if (!h || !actions || !obs || !reward || !done || (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
     if (h) h->error = "fleet_step_dev: null buffer or bad action dtype";
     return FLEET_ERR_INVALID;
@@ -752,6 +783,7 @@ int fleet_step_dev(fleet_handle h, const void* actions, int act_dtype, float* ob
 
 int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtype, float* obs, double* reward_sum,
                         int32_t* done_count) {
+  FLEET_ENTER(h);
   if (!h || K < 1 || !actions || !obs || !reward_sum || (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
     if (h) h->error = "fleet_step_many_dev: bad argument";
     return FLEET_ERR_INVALID;
@@ -772,6 +804,7 @@ int fleet_step_many_dev(fleet_handle h, int K, const void* actions, int act_dtyp
 }
 
 int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minute, int max_hours) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   // charging_hour may be 24 (the reference's own edge when the window would open exactly at midnight: never opens)
   if (charging_hour < 0 || charging_hour > 24 || charging_minute < 0 || charging_minute > 59 || max_hours < 0 ||
@@ -791,6 +824,7 @@ int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minut
 }
 
 int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count) {
+  FLEET_ENTER(h);
   if (!h || K < 1 || !obs || !reward_sum ||
       (policy != FLEET_ACT_POLICY_UNCONTROLLED && policy != FLEET_ACT_POLICY_DISTRIBUTED && policy != FLEET_ACT_POLICY_NIGHT)) {
     if (h) h->error = "fleet_rollout_policy_dev: bad argument";
@@ -815,6 +849,7 @@ int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, doub
 }
 
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs) {
+  FLEET_ENTER(h);
   if (!h || !obs) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t OD = (size_t)h->d.E * h->d.obs_dim * sizeof(float);
@@ -830,6 +865,7 @@ int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs) {
 
 int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
                     float* terminal_obs) {
+  FLEET_ENTER(h);
   if (!h || !actions || !obs || !reward || !done || (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
     if (h) h->error = "fleet_step_host: null buffer or bad action dtype";
     return FLEET_ERR_INVALID;
@@ -934,12 +970,14 @@ int fleet_step_host(fleet_handle h, const void* actions, int act_dtype, float* o
 }
 
 int fleet_last_step_error_bits(fleet_handle h, uint32_t* bits) {
+  FLEET_ENTER(h);
   if (!h || !bits) return FLEET_ERR_INVALID;
   *bits = h->last_step_err;
   return FLEET_OK;
 }
 
 int fleet_last_step_episodes(fleet_handle h, int32_t* n, const int32_t** env_idx, const double** ep_return, const int32_t** ep_len) {
+  FLEET_ENTER(h);
   if (!h || !n) return FLEET_ERR_INVALID;
   if (!h->host_step_has_episodes) {
     h->error = "fleet_last_step_episodes: needs a preceding fleet_step_host with a terminal_obs buffer";
@@ -982,6 +1020,7 @@ static size_t field_bytes(const FleetDev& d, int field) {
 }
 
 int fleet_get_dev(fleet_handle h, int field, void* out_dev) {
+  FLEET_ENTER(h);
   if (!h || !out_dev) return FLEET_ERR_INVALID;
   if (!field_bytes(h->d, field)) {
     h->error = "fleet_get_dev: unknown field";
@@ -993,6 +1032,7 @@ int fleet_get_dev(fleet_handle h, int field, void* out_dev) {
 }
 
 int fleet_get(fleet_handle h, int field, void* out) {
+  FLEET_ENTER(h);
   if (!h || !out) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t bytes = field_bytes(h->d, field);
@@ -1007,6 +1047,7 @@ int fleet_get(fleet_handle h, int field, void* out) {
 }
 
 int fleet_get_dist_factor(fleet_handle h, double* out) {
+  FLEET_ENTER(h);
   if (!h || !out) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, fleet_launch_dist_factor(h->d, h->st_dist, h->stream));
@@ -1051,6 +1092,7 @@ int fleet_rccl_comm_destroy(void* comm) {
 }
 
 int fleet_gather_episode_stats_rccl(fleet_handle h, void* comm, int world_size, double* out_dev) {
+  FLEET_ENTER(h);
   if (!h || !comm || world_size < 1 || !out_dev) {
     if (h) h->error = "fleet_gather_episode_stats_rccl: bad argument";
     return FLEET_ERR_INVALID;
@@ -1074,6 +1116,7 @@ int fleet_gather_episode_stats_rccl(fleet_handle h, void* comm, int world_size, 
 int fleet_log_capacity(fleet_handle h) { return (h && h->d.log_pos) ? h->d.log_cap : 0; }
 
 int fleet_log_dropped(fleet_handle h, int64_t* rows) {
+  FLEET_ENTER(h);
   if (!h || !rows || !h->d.log_pos) {
     if (h) h->error = "fleet_log_dropped: the data log is off or a null pointer";
     return FLEET_ERR_INVALID;
@@ -1089,6 +1132,7 @@ int fleet_log_dropped(fleet_handle h, int64_t* rows) {
 }
 
 int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, double* ev, float* obs) {
+  FLEET_ENTER(h);
   if (!h || !h->d.log_pos) {
     if (h) h->error = "fleet_log_read: the data log is off (FleetParams.log_data = 0)";
     return FLEET_ERR_INVALID;
@@ -1106,6 +1150,7 @@ int fleet_log_read(fleet_handle h, int32_t* pos, int32_t* row, double* env, doub
 }
 
 int fleet_log_clear(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h || !h->d.log_pos) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemsetAsync(h->d.log_pos, 0, (size_t)h->d.E * 4, h->stream));
@@ -1113,12 +1158,14 @@ int fleet_log_clear(fleet_handle h) {
 }
 
 int fleet_get_stream(fleet_handle h, void** hip_stream) {
+  FLEET_ENTER(h);
   if (!h || !hip_stream) return FLEET_ERR_INVALID;
   *hip_stream = static_cast<void*>(h->stream);
   return FLEET_OK;
 }
 
 int fleet_check_errors(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   std::vector<uint32_t> e(h->d.E);
   int rc = fleet_get(h, FLEET_F_ERROR_BITS, e.data());
@@ -1137,12 +1184,14 @@ int fleet_check_errors(fleet_handle h) {
 }
 
 int fleet_timer_start(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipEventRecord(h->ev_start, h->stream));
   return FLEET_OK;
 }
 
 int fleet_timer_stop(fleet_handle h, float* elapsed_ms) {
+  FLEET_ENTER(h);
   if (!h || !elapsed_ms) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipEventRecord(h->ev_stop, h->stream));
   HIP_TRY(h, hipEventSynchronize(h->ev_stop));
@@ -1151,12 +1200,14 @@ int fleet_timer_stop(fleet_handle h, float* elapsed_ms) {
 }
 
 int fleet_timer_mark(fleet_handle h) {
+  FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipEventRecord(h->ev_stop, h->stream));
   return FLEET_OK;
 }
 
 int fleet_timer_read(fleet_handle h, float* elapsed_ms) {
+  FLEET_ENTER(h);
   if (!h || !elapsed_ms) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipEventSynchronize(h->ev_stop));
   HIP_TRY(h, hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
@@ -1173,6 +1224,33 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
   const char* base = static_cast<const char*>(tape);
+  if (use_graph == FLEET_LAUNCH_DIRECT) {
+    // the library's own AQL packets: the launches of the run keep their state in the dies' L2s (fleet_direct.hip).  Asynchronous
+    // like the other forms; not on the HIP stream -- the next call on the handle (fleet_synchronize ...) waits for the run.
+    if (steps == 0) return FLEET_OK;
+    const bool stale = !h->direct || h->dq_tape != tape || h->dq_len != tape_len || h->dq_dtype != act_dtype || h->dq_obs != obs ||
+                       h->dq_reward != reward || h->dq_done != done;
+    if (stale) {
+      FLEET_ENTER(h);
+      if (!h->direct) {
+        const int rc = fleet_direct_open(h->device, &h->direct, &h->error);
+        if (rc != FLEET_OK) return rc;
+      }
+      FleetStepLaunch L;
+      const hipError_t e = fleet_describe_step(h->d, tape, act_dtype, obs, reward, done, nullptr, &L);
+      if (e != hipSuccess) {
+        h->error = "fleet_run_tape_dev: direct submission serves single-step launches only (no real_time, no data log)";
+        return FLEET_ERR_INVALID;
+      }
+      const int rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, &h->error);
+      if (rc != FLEET_OK) return rc;
+      h->dq_tape = tape; h->dq_len = tape_len; h->dq_dtype = act_dtype; h->dq_obs = obs; h->dq_reward = reward; h->dq_done = done;
+    }
+    // what the stream was given before the run (a reset, a copy of actions ...) has completed before its first packet is written
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return fleet_direct_submit(h->direct, steps, h->dq_timed, &h->error);
+  }
+  FLEET_ENTER(h);
   int i = 0;
   // the captured graph holds a whole number of tape cycles and at least 64 launches, however short the tape (a short tape must not
   // turn the replay into many short graphs: every hipGraphLaunch costs the host ~10 us)
@@ -1219,7 +1297,16 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
 int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                               double* reward, uint8_t* done, int use_graph) {
   if (!h || regions < 1 || regions > 256) return FLEET_ERR_INVALID;
+  FLEET_ENTER(h);
   HIP_TRY(h, hipSetDevice(h->device));
+  if (use_graph == FLEET_LAUNCH_DIRECT) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
+    h->dq_spans_us.clear();
+    h->dq_timed = true;
+    int rc = FLEET_OK;
+    for (int r = 0; r < regions && rc == FLEET_OK; ++r) rc = fleet_run_tape_dev(h, steps, tape, tape_len, act_dtype, obs, reward, done, use_graph);
+    h->dq_timed = false;
+    return rc;
+  }
   for (auto& e : h->region_events)
     if (e) (void)hipEventDestroy(e);
   h->region_events.assign(2 * (size_t)regions, nullptr);
@@ -1234,6 +1321,12 @@ int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void*
 }
 
 int fleet_time_regions_read(fleet_handle h, float* region_ms) {
+  FLEET_ENTER(h);
+  if (h && region_ms && h->region_events.empty() && !h->dq_spans_us.empty()) {  // (FLEET_ENTER has waited for the runs)
+    for (size_t r = 0; r < h->dq_spans_us.size(); ++r) region_ms[r] = (float)(h->dq_spans_us[r] * 1e-3);
+    h->dq_spans_us.clear();
+    return FLEET_OK;
+  }
   if (!h || !region_ms || h->region_events.empty()) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipEventSynchronize(h->region_events.back()));
   for (size_t r = 0; r < h->region_events.size() / 2; ++r)
@@ -1246,6 +1339,7 @@ int fleet_time_regions_read(fleet_handle h, float* region_ms) {
 
 int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                          double* reward, uint8_t* done, float* per_launch_ms) {
+  FLEET_ENTER(h);
   if (!h || steps < 1 || !tape || tape_len < 1 || !obs || !reward || !done || !per_launch_ms ||
       (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
     if (h) h->error = "fleet_time_steps_dev: bad argument";

@@ -246,6 +246,18 @@ hipError_t fleet_launch_reset(const FleetDev& d, const uint8_t* mask, float* obs
 int fleet_max_evs_per_lane_group();  // up to this many EVs per env the single-step kernel gives every EV a lane (fleet_kernels.hip kMaxGroup)
 hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                              uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s);
+// A single-step launch written down instead of issued (direct AQL submission, fleet_direct.hip): the host-side kernel symbol (its
+// name resolves the kernel in the code object), the launch geometry and the kernel-argument block; `actions_offset` = where the two
+// copies of the action pointer sit in it (a tape replay patches them per step).  host_fn == nullptr / hipErrorNotSupported: not a
+// single-step configuration (real_time, data log).
+struct FleetStepLaunch {
+  const void* host_fn;
+  unsigned grid, block, args_bytes;
+  unsigned actions_offset[2];
+  alignas(8) unsigned char args[512];
+};
+hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
+                               float* terminal_obs, FleetStepLaunch* out);
 // compact the terminal observations of the envs with done[e] != 0 (env order): idx[k], *count, compact[k, obs_dim]
 hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,
                                      double* ep_ret, int32_t* ep_len, float* compact, hipStream_t s);

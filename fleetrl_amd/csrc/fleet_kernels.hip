@@ -38,6 +38,8 @@
 // only), which reproduces the reference's full recount, including its cross-episode bookkeeping
 // (rainflow_length, quirk Q6), at O(stack depth) instead of O(history).
 #include "fleet_device.h"
+#include <cstddef>
+#include <cstring>
 
 #ifdef FLEET_STAMPS
 // Diagnostic build only (tools/stamps.py): s_memtime stamps of every wave (the first 4096) at fixed points of the step,
@@ -944,6 +946,27 @@ struct StepKernargPrefix {
   FleetDev d_arg;
 };
 static_assert(offsetof(StepKernargPrefix, d_arg) == 48 && alignof(FleetDev) == 8, "twelve preloaded dwords, then the argument block");
+// ... and the whole argument list: what a launch that does not go through hipLaunchKernel (fleet_describe_step: AQL packets written by
+// the library itself, fleet_direct.hip) puts into the kernel-argument segment.  Checked against the code object's metadata at load.
+struct StepKernargs {
+  const Hot* p_hot;
+  const SegRec* p_run;
+  const double* p_soh;
+  const void* p_actions;
+  int p_E, p_N;
+  EnvRec* p_env;
+  FleetDev d_arg;
+  const void* actions;
+  int act_mode, K;
+  float* obs;
+  double* reward;
+  uint8_t* done;
+  float* terminal_obs;
+  int32_t* done_count;
+};
+static_assert(offsetof(StepKernargs, d_arg) == offsetof(StepKernargPrefix, d_arg) && sizeof(StepKernargs) <= sizeof(FleetStepLaunch::args),
+              "the argument block of a described launch");
+thread_local FleetStepLaunch* t_describe = nullptr;  // set by fleet_describe_step around fleet_launch_step
 
 // What a K-step instance carries besides the action tape (MULTI only; round 5): the built-in policies and the event-skipping loop of
 // real_time each cost the tape rollout scalar registers it spills and branches it never takes -- compiled per use, the tape-only
@@ -1616,6 +1639,24 @@ void launch_many(const FleetDev& d, dim3 grid, dim3 block, const void* actions, 
 #undef FLEET_MANY
 }
 
+// A single-step launch goes to the HIP stream -- or, when fleet_describe_step asks, is written down instead: kernel, grid and the
+// argument block, for the AQL packets the library writes itself (fleet_direct.hip).
+inline void describe_launch(FleetStepLaunch* L, const void* host_fn, dim3 grid, dim3 block, const FleetDev& d, const void* actions,
+                            int act_mode, float* obs, double* reward, uint8_t* done, float* terminal_obs, int32_t* done_count) {
+  StepKernargs a{};
+  a.p_hot = d.hot; a.p_run = d.run; a.p_soh = d.soh; a.p_actions = actions; a.p_E = d.E; a.p_N = d.N; a.p_env = d.env;
+  a.d_arg = d; a.actions = actions; a.act_mode = act_mode; a.K = 1;
+  a.obs = obs; a.reward = reward; a.done = done; a.terminal_obs = terminal_obs; a.done_count = done_count;
+  L->host_fn = host_fn; L->grid = grid.x; L->block = block.x; L->args_bytes = (unsigned)sizeof a;
+  L->actions_offset[0] = (unsigned)offsetof(StepKernargs, p_actions); L->actions_offset[1] = (unsigned)offsetof(StepKernargs, actions);
+  memcpy(L->args, &a, sizeof a);
+}
+#define FLEET_LAUNCH_SINGLE(KERNEL, GRID)                                                                                              \
+  do {                                                                                                                                 \
+    if (t_describe) describe_launch(t_describe, (const void*)(KERNEL), GRID, block, d, actions, f64, obs, reward, done, terminal_obs, done_count); \
+    else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done, terminal_obs, done_count); \
+  } while (0)
+
 template <int G, int DEG>
 hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype, int K, float* obs, double* reward,
                           uint8_t* done, float* terminal_obs, int32_t* done_count, hipStream_t s) {
@@ -1624,6 +1665,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
   const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
+  if (t_describe && !single) return hipErrorNotSupported;  // only single-step launches are described
   // K steps per launch from a tape or a built-in policy keep one EV per lane too (not the event-skipping loop, not the data log)
   const bool many_grouped = (!single && !d.real_time && !d.log_pos);
   if (G == 64 && (single || many_grouped) && d.N > 64 && d.N <= kMaxGroup) {  // one EV per lane, two or four wavefronts per env
@@ -1636,26 +1678,21 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
     if (d.N <= 128) {
       const dim3 g2((d.E + 1) / 2);
       if (f64 == FLEET_ACT_F64)
-        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, false, false, false, true>), g2, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
-                           reward, done, terminal_obs, done_count);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG2, DEG, false, false, false, true>), g2);
       else
-        hipLaunchKernelGGL((fleet_step_kernel<GG2, DEG, false, false>), g2, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
-                           terminal_obs, done_count);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG2, DEG, false, false>), g2);
     } else {
       const dim3 g4(d.E);
       if (f64 == FLEET_ACT_F64)
-        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, false, false, false, true>), g4, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
-                           reward, done, terminal_obs, done_count);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG4, DEG, false, false, false, true>), g4);
       else
-        hipLaunchKernelGGL((fleet_step_kernel<GG4, DEG, false, false>), g4, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
-                           terminal_obs, done_count);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG4, DEG, false, false>), g4);
     }
     return hipGetLastError();
   }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, (G == 64)>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward,
-                         done, terminal_obs, done_count);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, (G == 64)>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64), true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
                          done, terminal_obs, done_count);
@@ -1663,11 +1700,9 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       launch_many<G, DEG, (G == 64)>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   } else {
     if (single && f64 == FLEET_ACT_F64)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs,
-                         reward, done, terminal_obs, done_count);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, false, false, true>), grid);
     else if (single)
-      hipLaunchKernelGGL((fleet_step_kernel<G, DEG, false, false>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done,
-                         terminal_obs, done_count);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, false>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
                          terminal_obs, done_count);
@@ -1722,6 +1757,16 @@ hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dty
 #define CALL(Gv) launch_step_g<Gv>(d, actions, act_dtype, K, obs, reward, done, terminal_obs, done_count, s)
   FLEET_DISPATCH_G(d.N, CALL)
 #undef CALL
+}
+
+hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
+                               float* terminal_obs, FleetStepLaunch* out) {
+  out->host_fn = nullptr;
+  t_describe = out;
+  const hipError_t e = fleet_launch_step(d, actions, act_dtype, 1, obs, reward, done, terminal_obs, nullptr, nullptr);
+  t_describe = nullptr;
+  if (e != hipSuccess) return e;
+  return out->host_fn ? hipSuccess : hipErrorNotSupported;
 }
 
 hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,

@@ -326,7 +326,21 @@ int fleet_timer_stop(fleet_handle h, float* elapsed_ms);  /* synchronises on the
 int fleet_timer_mark(fleet_handle h);
 int fleet_timer_read(fleet_handle h, float* elapsed_ms);
 /* launch `steps` single-step launches back to back from a device-resident action tape [tape_len,E,N]
- * (step i uses tape row i % tape_len); optionally through a captured hipGraph. */
+ * (step i uses tape row i % tape_len).  `use_graph`: how the launches reach the GPU --
+ *   FLEET_LAUNCH_EAGER   one hipLaunchKernel per step on the handle's stream
+ *   FLEET_LAUNCH_GRAPH   a captured hipGraph of whole tape cycles (>= 64 launches), replayed; shorter remainders eagerly
+ *   FLEET_LAUNCH_DIRECT  AQL dispatch packets written by the library into an HSA queue of the handle's own, with the cache
+ *                        actions HIP attaches to every kernel boundary reduced to what a run of steps needs: every launch still
+ *                        invalidates the per-CU caches, only the LAST launch of the run writes the L2s back.  A die's L2 then
+ *                        keeps the state of its envs from launch to launch (workgroup w of every launch runs on die w mod 8).
+ *                        Semantics: asynchronous like the others, but NOT on the HIP stream -- the run starts after everything
+ *                        the stream holds has completed (the call waits for that), nothing of it is visible before it has
+ *                        completed, and every later call on the handle (fleet_synchronize, a step, a get ...) waits for it first;
+ *                        fleet_stream_query reports it.  Single-step configurations only (no real_time, no data log);
+ *                        needs libfleet_hip.gfx950.hsaco beside the library (fleetrl_amd.build).  */
+#define FLEET_LAUNCH_EAGER 0
+#define FLEET_LAUNCH_GRAPH 1
+#define FLEET_LAUNCH_DIRECT 2
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
 
@@ -334,6 +348,7 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
  * with a HIP event before and after each: the kernels' own time per region, without the host's gaps between regions.
  * _begin only enqueues (several handles' streams can be filled before any is read); _read waits and returns the per-region
  * device durations in milliseconds (HOST array [regions]). */
+/* (FLEET_LAUNCH_DIRECT: the regions are the runs' own dispatch timestamps -- start of the first launch to end of the last) */
 int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype,
                              float* obs, double* reward, uint8_t* done, int use_graph);
 int fleet_time_regions_read(fleet_handle h, float* region_ms);
