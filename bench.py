@@ -94,7 +94,7 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def committed_traffic(config: str, envs: int, evs: int):
+def committed_traffic(config: str, envs: int, evs: int, launch_mode: str = "direct"):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
     profiles/r05_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
     The counters need rocprofv3, so they cannot be read inside this run: the figure is looked up, and `traffic_source` says so."""
@@ -103,10 +103,11 @@ def committed_traffic(config: str, envs: int, evs: int):
         if not os.path.isfile(path):
             continue
         t = json.load(open(path))
-        if t.get("kernel_src_sha") == kernel_source_sha() and (t.get("envs"), t.get("evs"), t.get("config")) == (envs, evs, config):
+        if t.get("kernel_src_sha") == kernel_source_sha() and (t.get("envs"), t.get("evs"), t.get("config")) == (envs, evs, config) \
+                and t.get("launch_mode", "graph") == launch_mode:
             return t.get("hbm_bytes_per_launch"), (f"profiles/{name}: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc passes of "
                                                    "this command on this kernel source (tools/prof_traffic.sh)")
-    return None, "no committed rocprofv3 PMC profile for this kernel source and shape"
+    return None, "no committed rocprofv3 PMC profile for this kernel source, shape and launch mode"
 
 
 def cpu_baseline(params, tables, time_feat, n_evs: int, budget_s: float = 8.0):
@@ -221,7 +222,7 @@ def main():
     ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
     ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--launch", choices=("graph", "eager", "direct"), default="graph",
+    ap.add_argument("--launch", choices=("graph", "eager", "direct"), default="direct",
                     help="how the K launches of a region reach the GPU: a replayed hipGraph (eager below 64 steps), one hipLaunchKernel "
                          "each, or AQL packets written by the library into a queue of its own without the L2 write-back HIP attaches "
                          "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT)")
@@ -292,9 +293,11 @@ def main():
     graph_len = L * ((64 + L - 1) // L)  # launches per captured graph: whole tape cycles, at least 64 (fleet_run_tape_dev)
     # launches go through a captured hipGraph of L steps; a run shorter than 64 steps launches eagerly (one graph launch costs
     # about as much as six kernel launches on the host: 9.9 vs 9.65 us per step measured for the driver's 20-step regions)
-    use_graph = int((not args.no_graph) and args.launch == "graph" and args.steps >= 64)
-    if args.launch == "direct":
-        use_graph = 2  # _capi.LAUNCH_DIRECT
+    launch_mode = "eager" if args.no_graph else args.launch
+    if launch_mode == "graph" and args.steps < 64:
+        launch_mode = "eager"
+    use_graph = {"eager": 0, "graph": 1, "direct": 2}[launch_mode]  # _capi.LAUNCH_*
+    launch_note = ""
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):
         lo, hi = shard_range(E, len(spec["groups"]), k)  # env groups in order: the first E % n groups hold one env more
@@ -312,6 +315,19 @@ def main():
 
     for g in groups:
         g.batch.reset_dev(g.obs.data_ptr())
+    if use_graph == 2:
+        # the library's own AQL queue needs its code object beside the library and an HSA agent for the device: where that is not
+        # to be had (an older build tree, a profiler that does not pass foreign queues) the run says so and replays a hipGraph
+        try:
+            for g in groups:
+                g.run(1, 2)
+            sync()
+        except Exception as ex:  # every rank decides alike only if the cause is in the tree; a lone failing rank raises below
+            launch_note = f"direct submission unavailable ({ex}); "
+            launch_mode = "graph" if args.steps >= 64 else "eager"
+            use_graph = {"eager": 0, "graph": 1}[launch_mode]
+        for g in groups:
+            g.batch.reset_dev(g.obs.data_ptr())
     # clock ramp: replay the same step (untimed) for a fixed wall time before the W warmup steps, so that a short
     # --steps/--warmup run measures the same steady state as a long one
     t_prime = time.perf_counter()
@@ -432,8 +448,9 @@ def main():
     out = None
     if rank == 0:
         # dominant kernel: fleet_step_kernel, one launch per step and group.  Average launch duration: HIP events on the
-        # kernels' streams around the timed region (graph-replayed launches, ~0.5 us of inter-kernel gap per launch included
-        # -> slightly conservative; rocprofv3's per-kernel average is in profiles/).  With several groups their streams run
+        # kernels' streams around the timed region -- or, for the library's own queue, the dispatch timestamps of the region's
+        # first and last packet (start of the first launch to end of the last) -- divided by the launches (the gaps between
+        # the launches are included -> slightly conservative; rocprofv3's per-kernel average is in profiles/).  With several groups their streams run
         # concurrently: the launch "duration" is the slowest stream's time per step, and the bytes are all groups' bytes.
         k_ms = max(ev_ms) / args.steps
         bytes_launch = sum(g.bytes_step * g.E for g in groups)
@@ -461,11 +478,12 @@ def main():
         if check:
             g0.batch.check_errors()
         fleets = "+".join(g.use_case for g in groups)
-        traffic, traffic_source = (committed_traffic(args.config, E, N) if not (args.deg or args.use_case)
+        traffic, traffic_source = (committed_traffic(args.config, E, N, launch_mode) if not (args.deg or args.use_case)
                                    else (None, "diagnostic override of the workload"))
         graph_used = use_graph == 1 and args.steps >= graph_len
-        launch_desc = (f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph != 2 else \
-            "AQL packets written by the library (own HSA queue): agent-scope acquire on every launch, L2 write-back only after the last of the region"
+        launch_desc = launch_note + ((f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph != 2 else
+                                     "AQL packets written by the library into an HSA queue of its own (FLEET_LAUNCH_DIRECT): every launch "
+                                     "invalidates the per-CU caches, only the last launch of a region writes the L2s back")
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -487,7 +505,7 @@ def main():
                                       "roof), a multi-GPU run of this config scales while every GPU idles" if args.config == "c4" else ""),
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
-                       "launch": launch_desc, "prime_ms": args.prime_ms,
+                       "launch": launch_desc, "launch_mode": launch_mode, "prime_ms": args.prime_ms,
                        "action_tape": f"{L} steps x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

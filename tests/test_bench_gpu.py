@@ -37,10 +37,19 @@ def test_bench_json_contract_single_gpu():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"] == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
     assert abs(d["value"] - 512 * 300 / (d["ms_per_step"] * 300 * 1e-3)) / d["value"] < 1e-9
-    assert d["config"]["launch"] == "hipGraph of 64 launches" and "timing" in d and d["errcheck"] is True
+    assert d["config"]["launch_mode"] == "direct" and "FLEET_LAUNCH_DIRECT" in d["config"]["launch"]  # the default: the library's own queue
+    assert "timing" in d and d["errcheck"] is True and r["kernel_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["episodes_gathered"] == 512
+
+
+def test_bench_through_a_replayed_hipgraph():
+    res = subprocess.run([sys.executable, "bench.py", "--launch", "graph", "--steps", "300", "--warmup", "20", "--envs-per-gpu", "512",
+                          "--prime-ms", "50", "--no-cpu-baseline", "--no-host-path"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = _json_line(res.stdout)
+    assert d["config"]["launch"] == "hipGraph of 64 launches" and d["config"]["launch_mode"] == "graph" and d["roofline"]["kernel_ms"] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():

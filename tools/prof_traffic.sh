@@ -24,7 +24,8 @@ if lines:
     j = json.loads(lines[-1])
     n_groups = len(j["config"]["groups"])
     res.update(groups=n_groups, envs=j["config"]["envs_per_gpu"], evs=j["config"]["evs_per_env"], config=j["config"]["name"],
-               algorithmic_bytes_per_launch=j["roofline"]["bytes_per_launch"], kernel=j["roofline"]["kernel"])
+               algorithmic_bytes_per_launch=j["roofline"]["bytes_per_launch"], kernel=j["roofline"]["kernel"],
+               launch_mode=j["config"].get("launch_mode", "graph"))
 for name in ("fetch", "write", "l2"):
     f = glob.glob(f"{out}/{name}/*/*counter_collection.csv")
     if not f:

@@ -38,7 +38,7 @@ static Kern symbol(hsa_executable_t exe, const char* name) {
   HSA_OK(hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.scratch));
   return k;
 }
-static void put(hsa_queue_t* q, const Kern& k, void* kargs, uint32_t blocks, int acq, int rel, hsa_signal_t done) {
+static void put(hsa_queue_t* q, const Kern& k, void* kargs, uint32_t blocks, int acq, int rel, hsa_signal_t done, int barrier = 1) {
   const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
   while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {}
   hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + (idx & (q->size - 1));
@@ -46,7 +46,7 @@ static void put(hsa_queue_t* q, const Kern& k, void* kargs, uint32_t blocks, int
   p->grid_size_x = blocks * 256; p->grid_size_y = 1; p->grid_size_z = 1;
   p->private_segment_size = k.scratch; p->group_segment_size = k.lds;
   p->kernel_object = k.obj; p->kernarg_address = kargs; p->reserved2 = 0; p->completion_signal = done;
-  const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+  const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier << HSA_PACKET_HEADER_BARRIER) |
                           (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
   const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
   __atomic_store_n((uint32_t*)p, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
@@ -126,6 +126,44 @@ int main(int argc, char** argv) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (n / 100 * 100);
     printf("HIP graph  %-8s %-28s %7.3f us per launch\n", names[ki], "", us);
     (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(st); (void)hipModuleUnload(mod);
+  }
+  // ---- dependent launches without the barrier bit (see the *_dep kernels): per-launch argument blocks carry the generation
+  {
+    struct DArgs { double* buf; int words; int pad; int* done; int gen; int flavor; int* err; };
+    const char* dn[3] = {"k_empty_dep", "k_touch_dep", "k_chain_dep"};
+    int* flags; HIP_OK(hipMalloc(&flags, (size_t)(blocks + 1) * 4));
+    char* dk; HIP_OK(hipMalloc(&dk, (size_t)n * 64));
+    for (int rep = 0; rep < 2; ++rep)
+    for (int ki = 0; ki < 3; ++ki) {
+      const Kern k = symbol(exe, dn[ki]);
+      for (int flavor = 0; flavor < 2; ++flavor)
+      for (int acqm = 0; acqm < 2; ++acqm) {
+        std::vector<char> hb((size_t)n * 64, 0);
+        for (int i = 0; i < n; ++i) { DArgs d{buf, words, 0, flags, i, flavor, flags + blocks}; memcpy(hb.data() + (size_t)i * 64, &d, sizeof d); }
+        HIP_OK(hipMemcpy(dk, hb.data(), hb.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMemset(buf, 0, (size_t)blocks * words * 8));
+        HIP_OK(hipMemset(flags, 0, (size_t)(blocks + 1) * 4));
+        HIP_OK(hipDeviceSynchronize());
+        hsa_signal_store_relaxed(done, 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; ++i) {
+          const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : (acqm ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
+          const int rel = (i == n - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
+          hsa_signal_t s{}; if (i == n - 1) s = done;
+          put(q, k, dk + (size_t)i * 64, blocks, acq, rel, s, i == 0 ? 1 : 0);
+        }
+        if (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 20ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) != 0) {
+          fprintf(stderr, "timeout waiting for the batch\n"); return 3;
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+        HIP_OK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
+        int errs = 0; HIP_OK(hipMemcpy(&errs, flags + blocks, 4, hipMemcpyDeviceToHost));
+        size_t bad = 0; const double want = ki == 0 ? 0.0 : (double)n;
+        for (double v : host) bad += (v != want);
+        printf("no barrier %-12s flag %-22s acquire %-5s %7.3f us per launch   wrong words %zu  gave up %d\n", dn[ki],
+               flavor == 0 ? "agent-scope atomics" : "sc0 load/store (L2)", acqm ? "agent" : "none", us, bad, errs);
+      }
+    }
   }
   hsa_queue_destroy(q);
   return 0;

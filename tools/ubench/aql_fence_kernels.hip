@@ -21,3 +21,55 @@ extern "C" __global__ __launch_bounds__(256) void k_chain(double* buf, int words
   for (int j = threadIdx.x; j < words; j += 256) c[j] += 1.0;
   if (acc < 0.0) c[0] = acc;  // never
 }
+
+// ---- dependent launches WITHOUT the barrier bit: workgroup w of launch g waits for workgroup w of launch g - 1 (a flag per
+// workgroup, written and polled inside the die's L2) instead of the whole launch waiting for the whole previous launch
+__device__ __forceinline__ int poll_flag(const int* p, int flavor) {
+  int v;
+  if (flavor == 0) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_turn(const int* done, int gen, int flavor, int* err) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (poll_flag(done + blockIdx.x, flavor) != gen && n < (1 << 14)) { __builtin_amdgcn_s_sleep(2); ++n; }
+    ok = n < (1 << 14);
+    if (!ok) atomicAdd(err, 1);
+  }
+  __syncthreads();
+  asm volatile("buffer_inv sc1" ::: "memory");  // the CU's vector cache may hold lines of this chunk from an earlier launch
+}
+__device__ __forceinline__ void pass_turn(int* done, int gen, int flavor) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have reached the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (flavor == 0) __hip_atomic_store(done + blockIdx.x, gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else asm volatile("global_store_dword %0, %1, off sc0" : : "v"(done + blockIdx.x), "v"(gen + 1) : "memory");
+  }
+}
+extern "C" __global__ __launch_bounds__(256) void k_empty_dep(double* buf, int words, int* done, int gen, int flavor, int* err) {
+  wait_turn(done, gen, flavor, err);
+  pass_turn(done, gen, flavor);
+}
+extern "C" __global__ __launch_bounds__(256) void k_touch_dep(double* buf, int words, int* done, int gen, int flavor, int* err) {
+  wait_turn(done, gen, flavor, err);
+  double* c = buf + (size_t)blockIdx.x * words;
+  for (int j = threadIdx.x; j < words; j += 256) c[j] += 1.0;
+  pass_turn(done, gen, flavor);
+}
+extern "C" __global__ __launch_bounds__(256) void k_chain_dep(double* buf, int words, int* done, int gen, int flavor, int* err) {
+  wait_turn(done, gen, flavor, err);
+  double* c = buf + (size_t)blockIdx.x * words;
+  int at = threadIdx.x;
+  double acc = 0.0;
+  for (int r = 0; r < 8; ++r) {
+    const double v = c[at];
+    acc += v;
+    at = (at * 5 + 17 + ((int)v & 1) * 32) & (words - 1);
+  }
+  for (int j = threadIdx.x; j < words; j += 256) c[j] += 1.0;
+  if (acc < 0.0) c[0] = acc;
+  pass_turn(done, gen, flavor);
+}
