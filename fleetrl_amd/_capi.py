@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2

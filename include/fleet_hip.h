@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 7
+#define FLEET_ABI_VERSION 8
 
 /* status codes */
 #define FLEET_OK 0

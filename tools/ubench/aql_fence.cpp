@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
   hsa_signal_t done; HSA_OK(hsa_signal_create(1, 0, nullptr, &done));
   std::vector<double> host((size_t)blocks * words);
   printf("%d workgroups x %d B, %d launches per figure\n", blocks, words * 8, n);
-  for (int rep = 0; rep < 2; ++rep)
+  for (int rep = 0; rep < 1; ++rep)
   for (int ki = 0; ki < 3; ++ki) {
     for (int mode = 0; mode < 3; ++mode) {
       // mode 0: agent/agent everywhere; 1: none/none inside the batch; 2: agent acquire, no release inside the batch
@@ -133,11 +133,12 @@ int main(int argc, char** argv) {
     const char* dn[3] = {"k_empty_dep", "k_touch_dep", "k_chain_dep"};
     int* flags; HIP_OK(hipMalloc(&flags, (size_t)(blocks + 1) * 4));
     char* dk; HIP_OK(hipMalloc(&dk, (size_t)n * 64));
-    for (int rep = 0; rep < 2; ++rep)
+    for (int rep = 0; rep < 1; ++rep)
     for (int ki = 0; ki < 3; ++ki) {
       const Kern k = symbol(exe, dn[ki]);
-      for (int flavor = 0; flavor < 2; ++flavor)
-      for (int acqm = 0; acqm < 2; ++acqm) {
+      for (int flavor = 1; flavor < 5; ++flavor)
+      for (int barrier = 0; barrier < 2; ++barrier)
+      for (int acqm = 0; acqm < 1; ++acqm) {
         std::vector<char> hb((size_t)n * 64, 0);
         for (int i = 0; i < n; ++i) { DArgs d{buf, words, 0, flags, i, flavor, flags + blocks}; memcpy(hb.data() + (size_t)i * 64, &d, sizeof d); }
         HIP_OK(hipMemcpy(dk, hb.data(), hb.size(), hipMemcpyHostToDevice));
@@ -150,7 +151,7 @@ int main(int argc, char** argv) {
           const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : (acqm ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE);
           const int rel = (i == n - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
           hsa_signal_t s{}; if (i == n - 1) s = done;
-          put(q, k, dk + (size_t)i * 64, blocks, acq, rel, s, i == 0 ? 1 : 0);
+          put(q, k, dk + (size_t)i * 64, blocks, acq, rel, s, (i == 0 || barrier) ? 1 : 0);
         }
         if (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 20ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_ACTIVE) != 0) {
           fprintf(stderr, "timeout waiting for the batch\n"); return 3;
@@ -160,8 +161,9 @@ int main(int argc, char** argv) {
         int errs = 0; HIP_OK(hipMemcpy(&errs, flags + blocks, 4, hipMemcpyDeviceToHost));
         size_t bad = 0; const double want = ki == 0 ? 0.0 : (double)n;
         for (double v : host) bad += (v != want);
-        printf("no barrier %-12s flag %-22s acquire %-5s %7.3f us per launch   wrong words %zu  gave up %d\n", dn[ki],
-               flavor == 0 ? "agent-scope atomics" : "sc0 load/store (L2)", acqm ? "agent" : "none", us, bad, errs);
+        const char* fl[5] = {"agent-scope flag, buffer_inv", "L2 flag, buffer_inv sc1", "L2 flag, state loads sc1", "L2 flag, state loads sc0 sc1", "L2 flag, plain loads (control)"};
+        printf("%-10s %-12s %-30s acquire %-5s %7.3f us per launch   wrong words %zu  gave up %d\n", barrier ? "barrier" : "no barrier", dn[ki],
+               fl[flavor], acqm ? "agent" : "none", us, bad, errs);
       }
     }
   }

@@ -39,7 +39,16 @@ __device__ __forceinline__ void wait_turn(const int* done, int gen, int flavor, 
     if (!ok) atomicAdd(err, 1);
   }
   __syncthreads();
-  asm volatile("buffer_inv sc1" ::: "memory");  // the CU's vector cache may hold lines of this chunk from an earlier launch
+  // the CU's vector cache may hold lines of this chunk from an earlier launch: invalidate it (flavors 0, 1) -- or let the loads of
+  // the chunk go past it (flavors 2, 3: ld_state) -- or do nothing (flavor 4: must lose updates, the control)
+  if (flavor <= 1) asm volatile("buffer_inv sc1" ::: "memory");
+}
+__device__ __forceinline__ double ld_state(const double* p, int flavor) {
+  double v;
+  if (flavor == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (flavor == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else v = *p;
+  return v;
 }
 __device__ __forceinline__ void pass_turn(int* done, int gen, int flavor) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's stores have reached the L2
@@ -56,7 +65,7 @@ extern "C" __global__ __launch_bounds__(256) void k_empty_dep(double* buf, int w
 extern "C" __global__ __launch_bounds__(256) void k_touch_dep(double* buf, int words, int* done, int gen, int flavor, int* err) {
   wait_turn(done, gen, flavor, err);
   double* c = buf + (size_t)blockIdx.x * words;
-  for (int j = threadIdx.x; j < words; j += 256) c[j] += 1.0;
+  for (int j = threadIdx.x; j < words; j += 256) c[j] = ld_state(c + j, flavor) + 1.0;
   pass_turn(done, gen, flavor);
 }
 extern "C" __global__ __launch_bounds__(256) void k_chain_dep(double* buf, int words, int* done, int gen, int flavor, int* err) {
@@ -65,11 +74,11 @@ extern "C" __global__ __launch_bounds__(256) void k_chain_dep(double* buf, int w
   int at = threadIdx.x;
   double acc = 0.0;
   for (int r = 0; r < 8; ++r) {
-    const double v = c[at];
+    const double v = ld_state(c + at, flavor);
     acc += v;
     at = (at * 5 + 17 + ((int)v & 1) * 32) & (words - 1);
   }
-  for (int j = threadIdx.x; j < words; j += 256) c[j] += 1.0;
+  for (int j = threadIdx.x; j < words; j += 256) c[j] = ld_state(c + j, flavor) + 1.0;
   if (acc < 0.0) c[0] = acc;
   pass_turn(done, gen, flavor);
 }
