@@ -107,6 +107,10 @@ struct FleetDirect {
   bool in_flight = false;
 };
 
+#ifdef FLEET_STAMPS
+static FleetDirect* g_last_direct = nullptr;  // diagnostic build only: whose code object fleet_debug_read_stamps_direct reads
+#endif
+
 static hsa_signal_t take_signal(FleetDirect* q) {
   hsa_signal_t s{};
   if (!q->pool.empty()) {
@@ -191,6 +195,9 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
     if (err) *err = hsa_err("loading the step kernels' code object", st);
     return fail(FLEET_ERR_HIP);
   }
+#ifdef FLEET_STAMPS
+  g_last_direct = q;
+#endif
   *out = q;
   return FLEET_OK;
 }
@@ -198,6 +205,9 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
 void fleet_direct_close(FleetDirect* q) {
   if (!q) return;
   if (q->in_flight) (void)fleet_direct_wait(q, nullptr, nullptr);
+#ifdef FLEET_STAMPS
+  if (g_last_direct == q) g_last_direct = nullptr;
+#endif
   if (q->queue) (void)hsa_queue_destroy(q->queue);
   for (hsa_signal_t s : q->pool) (void)hsa_signal_destroy(s);
   if (q->have_exe) (void)hsa_executable_destroy(q->exe);
@@ -207,6 +217,20 @@ void fleet_direct_close(FleetDirect* q) {
   if (q->hsa_up) (void)hsa_shut_down();
   delete q;
 }
+
+#ifdef FLEET_STAMPS
+// Diagnostic build only (tools/stamps.py): the stamp buffer of the code object THIS queue's kernels run from (the HSA-loaded copy has
+// a buffer of its own, which hipMemcpyFromSymbol does not see)
+extern "C" int fleet_debug_read_stamps_direct(unsigned long long* out, size_t bytes) {
+  if (!g_last_direct) return -1;
+  hsa_executable_symbol_t sym;
+  uint64_t addr = 0;
+  if (hsa_executable_get_symbol_by_name(g_last_direct->exe, "fleet_stamp_buf", &g_last_direct->agent, &sym) != HSA_STATUS_SUCCESS ||
+      hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr) != HSA_STATUS_SUCCESS)
+    return -2;
+  return (int)hipMemcpy(out, reinterpret_cast<const void*>(addr), bytes, hipMemcpyDeviceToHost);
+}
+#endif
 
 int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* tape, int tape_len, size_t row_bytes, std::string* err) {
   if (!q || !L.host_fn || tape_len < 1 || L.args_bytes > FleetDirect::kBlockBytes) return FLEET_ERR_INVALID;

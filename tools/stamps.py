@@ -31,17 +31,23 @@ done = torch.empty(E, device=dev, dtype=torch.uint8)
 b.reset_dev(obs.data_ptr())
 import time as _time
 _n = int(os.environ.get("STEPS", 300))
-b.run_tape_dev(_n - 2000 if _n > 4000 else 0, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=False)  # STEPS=20000: the steady state bench.py measures
+LAUNCH = int(os.environ.get("LAUNCH", 0))  # 0: one hipLaunchKernel per step; 2: the library's own queue (FLEET_LAUNCH_DIRECT)
+b.run_tape_dev(_n - 2000 if _n > 4000 else 0, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=LAUNCH)  # STEPS=20000: the steady state bench.py measures
 b.synchronize()
 _t0 = _time.perf_counter()
-b.run_tape_dev(2000 if _n > 4000 else _n, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=False)
+b.run_tape_dev(2000 if _n > 4000 else _n, tape.data_ptr(), 16, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), use_graph=LAUNCH)
 b.synchronize()
-print("launch period (eager, stamped build): %.2f us" % ((_time.perf_counter() - _t0) * 1e6 / (2000 if _n > 4000 else _n)))
+print("launch period (%s, stamped build)" % ('own queue' if LAUNCH == 2 else 'eager') + " "
+      ": %.2f us" % ((_time.perf_counter() - _t0) * 1e6 / (2000 if _n > 4000 else _n)))
 lib = _capi.load_library()
 SLOTS = 32
 buf = np.zeros(4096 * SLOTS, dtype=np.uint64)
-lib.fleet_debug_read_stamps.argtypes = [C.c_void_p]
-assert lib.fleet_debug_read_stamps(buf.ctypes.data) == 0
+if LAUNCH == 2:  # the kernels ran from the code object the library loaded through HSA: its own stamp buffer
+    lib.fleet_debug_read_stamps_direct.argtypes = [C.c_void_p, C.c_size_t]
+    assert lib.fleet_debug_read_stamps_direct(buf.ctypes.data, buf.nbytes) == 0
+else:
+    lib.fleet_debug_read_stamps.argtypes = [C.c_void_p]
+    assert lib.fleet_debug_read_stamps(buf.ctypes.data) == 0
 s = buf.reshape(4096, SLOTS)[: min(E, 4096), :9].astype(np.int64)  # one row per wavefront (G = 64: one env each)
 valid = (s > 0).all(axis=1)
 s = s[valid]
