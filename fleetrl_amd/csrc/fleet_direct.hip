@@ -1,15 +1,19 @@
 // Direct AQL submission: a run of single-step launches written into an HSA queue by the library itself (host code only).
 //
 // Why: HIP gives every kernel packet an agent-scope acquire AND release fence.  On a part whose eight dies have an L2 each, not
-// coherent with one another, the release is a write-back of the die's dirty lines at the end of EVERY launch, and the next launch
-// fetches its state from beyond the L2 again.  Between two steps of the same batch none of that is needed: workgroup w -- and the
+// coherent with one another, the release is a write-back of the die's dirty lines at the end of EVERY launch -- the next launch waits
+// for it to drain and then fetches its state from beyond the L2 again.  Between two steps of the same batch none of that is needed: workgroup w -- and the
 // hardware hands workgroup w of a grid to die w mod 8 -- owns the same envs in every launch, so every byte of state a die reads was
 // last written by itself (or by nobody: tables, actions).  A run submitted here keeps the acquire (the per-CU vector caches and the
 // scalar caches ARE invalidated at every launch: a wavefront of env e runs on another CU of its die next time) and drops the release
 // on all packets but the last, which releases at system scope: after the run every result is where any reader expects it.
 // tools/ubench/aql_fence.cpp is the microbenchmark of the effect (read-modify-write of 16 MB by 4096 workgroups: 5.3 -> 2.9 us per
 // launch, empty launch 1.56 -> 1.44 us; results identical over 2000 launches); tests/test_direct_gpu.py holds the step kernel to
-// bit-identical state, observations and rewards against the HIP-stream path.
+// bit-identical state, observations and rewards against the HIP-stream path.  What the step kernel gains (in-kernel stamps,
+// profiles/r05_experiments/direct_queue_stamps_by_batch.log): up to ~1000 envs x 50 EVs the state records really are served by the
+// die's L2 (first loads back after 750 instead of 1140 cycles); from 2048 envs on a launch turns over more lines per die than the L2
+// holds and the gain is the shorter launch floor plus the write-back that no longer has to drain between launches
+// (4096 x 50: 8.0 -> 6.45 us per step).
 //
 // What a caller may rely on: nothing of the run is visible before it has completed (fleet_synchronize / the next call on the handle
 // waits for it), everything after.  What the library relies on: the single-step kernels touch an env's state only from that env's
@@ -339,9 +343,12 @@ bool fleet_direct_busy(FleetDirect* q) { return q && q->in_flight && hsa_signal_
 int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string* err) {
   if (!q) return FLEET_ERR_INVALID;
   if (q->in_flight) {
-    // 60 s: a run of 16384 launches of the largest batch is ~1 s
-    const uint64_t ticks = q->tick_hz ? q->tick_hz * 60ull : UINT64_MAX;
-    if (hsa_signal_wait_scacquire(q->last, HSA_SIGNAL_CONDITION_LT, 1, ticks, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    // spin for the first millisecond (a caller that polls -- fleet_stream_query -- never gets here before the run is done; one that
+    // synchronises right after a short run wants it back within microseconds), then sleep on the signal's interrupt.
+    // 60 s in all: a run of 16384 launches of the largest batch is ~1 s
+    const uint64_t hz = q->tick_hz ? q->tick_hz : 100000000ull;
+    if (hsa_signal_wait_scacquire(q->last, HSA_SIGNAL_CONDITION_LT, 1, hz / 1000, HSA_WAIT_STATE_ACTIVE) >= 1 &&
+        hsa_signal_wait_scacquire(q->last, HSA_SIGNAL_CONDITION_LT, 1, hz * 60ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
       if (err) *err = "fleet_direct_wait: the run did not complete within 60 s";
       return FLEET_ERR_HIP;
     }

@@ -331,8 +331,9 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
  *   FLEET_LAUNCH_GRAPH   a captured hipGraph of whole tape cycles (>= 64 launches), replayed; shorter remainders eagerly
  *   FLEET_LAUNCH_DIRECT  AQL dispatch packets written by the library into an HSA queue of the handle's own, with the cache
  *                        actions HIP attaches to every kernel boundary reduced to what a run of steps needs: every launch still
- *                        invalidates the per-CU caches, only the LAST launch of the run writes the L2s back.  A die's L2 then
- *                        keeps the state of its envs from launch to launch (workgroup w of every launch runs on die w mod 8).
+ *                        invalidates the per-CU caches, only the LAST launch of the run writes the L2s back: no launch
+ *                        waits for the previous one's write-back (workgroup w of every launch runs on die w mod 8, so a die
+ *                        only reads state it wrote itself).
  *                        Semantics: asynchronous like the others, but NOT on the HIP stream -- the run starts after everything
  *                        the stream holds has completed (the call waits for that), nothing of it is visible before it has
  *                        completed, and every later call on the handle (fleet_synchronize, a step, a get ...) waits for it first;

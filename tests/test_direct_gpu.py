@@ -122,3 +122,35 @@ def test_direct_is_refused_where_it_does_not_apply():
     with pytest.raises(Exception, match="single-step"):
         b.run_tape_dev(4, tape.data_ptr(), 4, obs.data_ptr(), r.data_ptr(), d.data_ptr(), use_graph=_capi.LAUNCH_DIRECT)
     b.close()
+
+
+def test_direct_float64_tape_and_two_handles_in_flight():
+    """The float64-action instance through the queue, and two handles (two queues) with runs in flight at the same time."""
+    import torch
+
+    g, a, b, rng = _pair("ct5_both_rainflow", 400)
+    _, c, d, _ = _pair("lmd1_price_linear", 300, seed=12)
+    acts = rng.uniform(-1, 1, size=(13, 400, g.N))
+    acts2 = rng.uniform(-1, 1, size=(13, 300, c.N)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    t64, t32 = torch.from_numpy(acts).to(dev), torch.from_numpy(acts2).to(dev)
+
+    def bufs(x):
+        o = (torch.zeros((x.E, x.obs_dim), device=dev), torch.zeros(x.E, device=dev, dtype=torch.float64), torch.zeros(x.E, device=dev, dtype=torch.uint8))
+        x.reset_dev(o[0].data_ptr())
+        return o
+
+    ba, bb, bc, bd = bufs(a), bufs(b), bufs(c), bufs(d)
+    a.run_tape_dev(150, t64.data_ptr(), 13, *(t.data_ptr() for t in ba), use_graph=_capi.LAUNCH_EAGER, act_dtype=_capi.ACT_F64)
+    c.run_tape_dev(220, t32.data_ptr(), 13, *(t.data_ptr() for t in bc), use_graph=_capi.LAUNCH_EAGER)
+    b.run_tape_dev(150, t64.data_ptr(), 13, *(t.data_ptr() for t in bb), use_graph=_capi.LAUNCH_DIRECT, act_dtype=_capi.ACT_F64)
+    d.run_tape_dev(220, t32.data_ptr(), 13, *(t.data_ptr() for t in bd), use_graph=_capi.LAUNCH_DIRECT)  # while b's run is in flight
+    for x in (a, b, c, d):
+        x.synchronize()
+    for want, got, x, y in ((ba, bb, a, b), (bc, bd, c, d)):
+        for k in range(3):
+            np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy())
+        for f in STATE:
+            np.testing.assert_array_equal(y.get(f), x.get(f), err_msg=f)
+    for x in (a, b, c, d):
+        x.close()
