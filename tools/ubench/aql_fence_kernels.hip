@@ -82,3 +82,11 @@ extern "C" __global__ __launch_bounds__(256) void k_chain_dep(double* buf, int w
   if (acc < 0.0) c[0] = acc;
   pass_turn(done, gen, flavor);
 }
+
+// read the workgroup's chunk, write one word: how much CLEAN data a die's L2 carries from launch to launch (k_touch: dirty data)
+extern "C" __global__ __launch_bounds__(256) void k_read(double* buf, int words) {
+  double* c = buf + (size_t)blockIdx.x * words;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < words - 256; j += 256) acc += c[j];
+  c[words - 256 + threadIdx.x] = acc * 0.0 + c[words - 256 + threadIdx.x] + 1.0;
+}
