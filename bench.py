@@ -222,10 +222,11 @@ def main():
     ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
     ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--launch", choices=("graph", "eager", "direct"), default="direct",
+    ap.add_argument("--launch", choices=("graph", "eager", "direct", "direct1"), default="direct",
                     help="how the K launches of a region reach the GPU: a replayed hipGraph (eager below 64 steps), one hipLaunchKernel "
                          "each, or AQL packets written by the library into a queue of its own without the L2 write-back HIP attaches "
-                         "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT)")
+                         "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT; a batch of >= 6144 wavefronts goes to two queues, "
+                         "direct1 keeps it on one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--tape-len", type=int, default=None,
@@ -296,7 +297,7 @@ def main():
     launch_mode = "eager" if args.no_graph else args.launch
     if launch_mode == "graph" and args.steps < 64:
         launch_mode = "eager"
-    use_graph = {"eager": 0, "graph": 1, "direct": 2}[launch_mode]  # _capi.LAUNCH_*
+    use_graph = {"eager": 0, "graph": 1, "direct": 2, "direct1": 3}[launch_mode]  # _capi.LAUNCH_*
     launch_note = ""
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):
@@ -315,12 +316,12 @@ def main():
 
     for g in groups:
         g.batch.reset_dev(g.obs.data_ptr())
-    if use_graph == 2:
+    if use_graph >= 2:
         # the library's own AQL queue needs its code object beside the library and an HSA agent for the device: where that is not
         # to be had (an older build tree, a profiler that does not pass foreign queues) the run says so and replays a hipGraph
         try:
             for g in groups:
-                g.run(1, 2)
+                g.run(1, use_graph)
             sync()
         except Exception as ex:  # every rank decides alike only if the cause is in the tree; a lone failing rank raises below
             launch_note = f"direct submission unavailable ({ex}); "
@@ -481,9 +482,12 @@ def main():
         traffic, traffic_source = (committed_traffic(args.config, E, N, launch_mode) if not (args.deg or args.use_case)
                                    else (None, "diagnostic override of the workload"))
         graph_used = use_graph == 1 and args.steps >= graph_len
-        launch_desc = launch_note + ((f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph != 2 else
-                                     "AQL packets written by the library into an HSA queue of its own (FLEET_LAUNCH_DIRECT): every launch "
-                                     "invalidates the per-CU caches, only the last launch of a region writes the L2s back")
+        n_queues = max(g.batch.direct_queues() for g in groups) if use_graph >= 2 else 0
+        launch_desc = launch_note + ((f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph < 2 else
+                                     "AQL packets written by the library into " + ("an HSA queue" if n_queues < 2 else "two HSA queues") +
+                                     " of its own (FLEET_LAUNCH_DIRECT): every launch invalidates the per-CU caches, only the last launch "
+                                     "of a region writes the L2s back" +
+                                     ("; the batch as two ranges of workgroups, one in-order chain per queue" if n_queues == 2 else ""))
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -505,7 +509,7 @@ def main():
                                       "roof), a multi-GPU run of this config scales while every GPU idles" if args.config == "c4" else ""),
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
-                       "launch": launch_desc, "launch_mode": launch_mode, "prime_ms": args.prime_ms,
+                       "launch": launch_desc, "launch_mode": launch_mode, "launches_per_step": len(groups) * max(1, n_queues), "prime_ms": args.prime_ms,
                        "action_tape": f"{L} steps x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -18,7 +18,7 @@ DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
 PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
 # fleet_run_tape_dev / fleet_time_regions_begin: how the launches reach the GPU (include/fleet_hip.h FLEET_LAUNCH_*)
-LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT = 0, 1, 2
+LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT, LAUNCH_DIRECT_ONE_QUEUE = 0, 1, 2, 3
 POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
 DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL = 1, 2, 4, 8, 16, 32
@@ -215,6 +215,9 @@ def load_library():
     lib.fleet_rccl_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.fleet_rccl_comm_destroy.argtypes = [vp]
     lib.fleet_gather_episode_stats_rccl.argtypes = [vp, vp, C.c_int, vp]
+    if hasattr(lib, "fleet_direct_queues"):  # (absent from older libraries the A/B scripts run beside the tree's)
+        lib.fleet_direct_queues.argtypes = [vp]
+        lib.fleet_direct_queues.restype = C.c_int
     if hasattr(lib, "fleet_selftest_division"):  # (absent from the round-4 library the A/B scripts run beside the tree's)
         lib.fleet_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.fleet_selftest_division.restype = C.c_int
@@ -241,5 +244,5 @@ EXPORTED_SYMBOLS = (
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
-    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division",
+    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues",
 )

@@ -300,6 +300,10 @@ class FleetBatch:
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
                                                  reward_ptr, done_ptr, int(use_graph)))
 
+    def direct_queues(self) -> int:
+        """How the handle's last direct run (use_graph=_capi.LAUNCH_DIRECT) was laid out: 0 none yet, 1 one queue, 2 two queues."""
+        return int(self.lib.fleet_direct_queues(self.h)) if hasattr(self.lib, "fleet_direct_queues") else 0
+
     def time_steps_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
                        act_dtype: int = _capi.ACT_F32) -> np.ndarray:
         """Per-launch device durations [ms] measured with one HIP event pair per launch on the handle's stream."""

@@ -128,7 +128,7 @@ struct Batch {
   // argument blocks describe, the spans of the timed runs waited for so far
   FleetDirect* direct = nullptr;
   const void* dq_tape = nullptr;
-  int dq_len = 0, dq_dtype = 0;
+  int dq_len = 0, dq_dtype = 0, dq_mode = 0;
   float* dq_obs = nullptr;
   double* dq_reward = nullptr;
   uint8_t* dq_done = nullptr;
@@ -196,6 +196,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->abi_version != FLEET_ABI_VERSION) return "abi_version mismatch";
   if (p->struct_bytes != (int)sizeof(FleetParams)) return "FleetParams size mismatch";
   if (p->num_envs < 1 || p->num_cars < 1 || p->table_rows < 2) return "num_envs/num_cars/table_rows out of range";
+  if (p->num_cars > 65535) return "num_cars: at most 65535 EVs per env";  // (the step kernel's packed argument, fleet_kernels.hip `p_N`)
   if (p->episode_steps < 1 || p->steps_per_hour < 1) return "episode_steps/steps_per_hour out of range";
   if (p->price_lookahead < 0 || p->bl_pv_lookahead < 0) return "negative look-ahead";
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
@@ -1224,12 +1225,12 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
   const char* base = static_cast<const char*>(tape);
-  if (use_graph == FLEET_LAUNCH_DIRECT) {
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {
     // the library's own AQL packets: the launches of the run keep their state in the dies' L2s (fleet_direct.hip).  Asynchronous
     // like the other forms; not on the HIP stream -- the next call on the handle (fleet_synchronize ...) waits for the run.
     if (steps == 0) return FLEET_OK;
     const bool stale = !h->direct || h->dq_tape != tape || h->dq_len != tape_len || h->dq_dtype != act_dtype || h->dq_obs != obs ||
-                       h->dq_reward != reward || h->dq_done != done;
+                       h->dq_reward != reward || h->dq_done != done || h->dq_mode != use_graph;
     if (stale) {
       FLEET_ENTER(h);
       if (!h->direct) {
@@ -1242,8 +1243,15 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
         h->error = "fleet_run_tape_dev: direct submission serves single-step launches only (no real_time, no data log)";
         return FLEET_ERR_INVALID;
       }
-      const int rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, &h->error);
+      // a batch of more wavefronts than are resident at once (256 CUs x 4 SIMDs x 5 of this kernel = 5120) runs as two ranges of
+      // workgroups on two queues; one wavefront per env or less only (the wider groups were not measured to gain)
+#ifndef FLEET_DIRECT_SPLIT_WAVES
+#define FLEET_DIRECT_SPLIT_WAVES 6144
+#endif
+      const bool split = use_graph == FLEET_LAUNCH_DIRECT && h->d.N <= 64 && (size_t)L.grid * (L.block / 64) >= FLEET_DIRECT_SPLIT_WAVES;
+      const int rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, split, &h->error);
       if (rc != FLEET_OK) return rc;
+      h->dq_mode = use_graph;
       h->dq_tape = tape; h->dq_len = tape_len; h->dq_dtype = act_dtype; h->dq_obs = obs; h->dq_reward = reward; h->dq_done = done;
     }
     // what the stream was given before the run (a reset, a copy of actions ...) has completed before its first packet is written
@@ -1294,12 +1302,17 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   return FLEET_OK;
 }
 
+int fleet_direct_queues(fleet_handle h) {
+  if (!h) return FLEET_ERR_INVALID;
+  return h->direct ? fleet_direct_parts(h->direct) : 0;
+}
+
 int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                               double* reward, uint8_t* done, int use_graph) {
   if (!h || regions < 1 || regions > 256) return FLEET_ERR_INVALID;
   FLEET_ENTER(h);
   HIP_TRY(h, hipSetDevice(h->device));
-  if (use_graph == FLEET_LAUNCH_DIRECT) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
     h->dq_spans_us.clear();
     h->dq_timed = true;
     int rc = FLEET_OK;

@@ -254,6 +254,7 @@ struct FleetStepLaunch {
   const void* host_fn;
   unsigned grid, block, args_bytes;
   unsigned actions_offset[2];
+  unsigned packed_n_offset;  // where `p_N` sits: EVs per env | first workgroup of the grid << 16 (a run split over two queues)
   alignas(8) unsigned char args[512];
 };
 hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,

@@ -91,7 +91,7 @@ std::string code_object_path() {
 struct FleetDirect {
   int device = 0;
   hsa_agent_t agent{};
-  hsa_queue_t* queue = nullptr;
+  hsa_queue_t* queue[2] = {nullptr, nullptr};  // the second one is created when a run is split (fleet_direct_prepare)
   hsa_executable_t exe{};
   hsa_code_object_reader_t reader{};
   bool have_exe = false, have_reader = false, hsa_up = false;
@@ -100,14 +100,19 @@ struct FleetDirect {
   std::map<std::string, KernelObject> kernels;
   // the prepared launch
   KernelObject kernel;
-  unsigned grid = 0, block = 0;
-  char* kargs_dev = nullptr;  // tape_len blocks of kBlockBytes
+  unsigned block = 0;
+  int parts = 1;              // 1: the whole grid on queue 0; 2: the grid as two ranges of workgroups, one per queue
+  unsigned part_grid[2] = {0, 0};
+  char* kargs_dev = nullptr;  // parts x tape_len blocks of kBlockBytes (part-major)
   size_t kargs_cap = 0;
   int tape_len = 0;
   static constexpr size_t kBlockBytes = 512;
-  // signals: a pool; the ones handed out since the last wait; (first, last) of every timed run among them; the newest run's last
-  std::vector<hsa_signal_t> pool, pending, marks;
-  hsa_signal_t last{};
+  // signals: a pool; the ones handed out since the last wait; per timed run and queue (first, last) among them; per queue the newest
+  // run's last
+  std::vector<hsa_signal_t> pool, pending;
+  struct Mark { hsa_signal_t first[2], last[2]; int parts; };
+  std::vector<Mark> marks;
+  hsa_signal_t last[2] = {};
   bool in_flight = false;
 };
 
@@ -125,6 +130,27 @@ static hsa_signal_t take_signal(FleetDirect* q) {
   }
   if (hsa_signal_create(1, 0, nullptr, &s) != HSA_STATUS_SUCCESS) s.handle = 0;
   return s;
+}
+
+static int open_queue(FleetDirect* q, int k, std::string* err) {
+  if (q->queue[k]) return FLEET_OK;
+  uint32_t qmax = 0;
+  (void)hsa_agent_get_info(q->agent, HSA_AGENT_INFO_QUEUE_MAX_SIZE, &qmax);
+  uint32_t qsize = 16384;
+  while (qmax && qsize > qmax) qsize >>= 1;
+  hsa_status_t st = hsa_queue_create(q->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q->queue[k]);
+  if (st != HSA_STATUS_SUCCESS) {
+    q->queue[k] = nullptr;
+    if (err) *err = hsa_err("hsa_queue_create", st);
+    return FLEET_ERR_HIP;
+  }
+  // dispatch timestamps in the completion signals (read for the packets that carry one: the first and last of a timed run).  Enabled
+  // before the queue's first packet: the switch is not seen by a queue that is already running.
+  if ((st = hsa_amd_profiling_set_profiler_enabled(q->queue[k], 1)) != HSA_STATUS_SUCCESS) {
+    if (err) *err = hsa_err("hsa_amd_profiling_set_profiler_enabled", st);
+    return FLEET_ERR_HIP;
+  }
+  return FLEET_OK;
 }
 
 int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
@@ -162,22 +188,8 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
     return fail(FLEET_ERR_INVALID);
   }
   (void)hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &q->tick_hz);
-  uint32_t qmax = 0;
-  (void)hsa_agent_get_info(q->agent, HSA_AGENT_INFO_QUEUE_MAX_SIZE, &qmax);
-  uint32_t qsize = 16384;
-  while (qmax && qsize > qmax) qsize >>= 1;
-  st = hsa_queue_create(q->agent, qsize, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q->queue);
-  if (st != HSA_STATUS_SUCCESS) {
-    q->queue = nullptr;
-    if (err) *err = hsa_err("hsa_queue_create", st);
-    return fail(FLEET_ERR_HIP);
-  }
-  // dispatch timestamps in the completion signals (read for the packets that carry one: the first and last of a timed run).  Enabled
-  // before the queue's first packet: the switch is not seen by a queue that is already running.
-  if ((st = hsa_amd_profiling_set_profiler_enabled(q->queue, 1)) != HSA_STATUS_SUCCESS) {
-    if (err) *err = hsa_err("hsa_amd_profiling_set_profiler_enabled", st);
-    return fail(FLEET_ERR_HIP);
-  }
+  const int rcq = open_queue(q, 0, err);
+  if (rcq != FLEET_OK) return fail(rcq);
   const std::string path = code_object_path();
   q->fd = open(path.c_str(), O_RDONLY);
   if (q->fd < 0) {
@@ -212,7 +224,8 @@ void fleet_direct_close(FleetDirect* q) {
 #ifdef FLEET_STAMPS
   if (g_last_direct == q) g_last_direct = nullptr;
 #endif
-  if (q->queue) (void)hsa_queue_destroy(q->queue);
+  for (hsa_queue_t* hq : q->queue)
+    if (hq) (void)hsa_queue_destroy(hq);
   for (hsa_signal_t s : q->pool) (void)hsa_signal_destroy(s);
   if (q->have_exe) (void)hsa_executable_destroy(q->exe);
   if (q->have_reader) (void)hsa_code_object_reader_destroy(q->reader);
@@ -236,7 +249,8 @@ extern "C" int fleet_debug_read_stamps_direct(unsigned long long* out, size_t by
 }
 #endif
 
-int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* tape, int tape_len, size_t row_bytes, std::string* err) {
+int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* tape, int tape_len, size_t row_bytes, bool split,
+                         std::string* err) {
   if (!q || !L.host_fn || tape_len < 1 || L.args_bytes > FleetDirect::kBlockBytes) return FLEET_ERR_INVALID;
   if (q->in_flight) {
     if (err) *err = "fleet_direct_prepare: a run is in flight";
@@ -265,9 +279,23 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
     return FLEET_ERR_STATE;
   }
   q->kernel = it->second;
-  q->grid = L.grid;
   q->block = L.block;
-  const size_t need = (size_t)tape_len * FleetDirect::kBlockBytes;
+  // one grid on one queue -- or, for a batch of more wavefronts than are resident at once, two ranges of workgroups on two queues,
+  // each an in-order chain of its own: the two halves drift apart and one's loads run under the other's arithmetic and stores
+  // (16384 x 50: 24.5 -> 20.9 us per step; no gain at 4096 x 50, profiles/r05_experiments/direct_queue_two_handles.log).  The second
+  // range's workgroups continue the numbering of the first (the kernel's packed `p_N`), so env e stays workgroup e / (256 / G) and
+  // keeps its die; the first range is a multiple of 8 workgroups.
+  q->parts = (split && L.grid >= 16) ? 2 : 1;
+  if (q->parts == 2) {
+    const int rc = open_queue(q, 1, err);
+    if (rc != FLEET_OK) return rc;
+    q->part_grid[0] = ((L.grid / 2 + 7) / 8) * 8;
+    q->part_grid[1] = L.grid - q->part_grid[0];
+  } else {
+    q->part_grid[0] = L.grid;
+    q->part_grid[1] = 0;
+  }
+  const size_t need = (size_t)q->parts * tape_len * FleetDirect::kBlockBytes;
   if (need > q->kargs_cap) {
     if (q->kargs_dev) (void)hipFree(q->kargs_dev);
     q->kargs_dev = nullptr;
@@ -279,13 +307,20 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
     q->kargs_cap = need;
   }
   std::vector<unsigned char> host(need, 0);
-  for (int k = 0; k < tape_len; ++k) {
-    unsigned char* b = host.data() + (size_t)k * FleetDirect::kBlockBytes;
-    memcpy(b, L.args, L.args_bytes);
-    const void* row = static_cast<const char*>(tape) + (size_t)k * row_bytes;
-    memcpy(b + L.actions_offset[0], &row, sizeof row);
-    memcpy(b + L.actions_offset[1], &row, sizeof row);
-  }
+  for (int part = 0; part < q->parts; ++part)
+    for (int k = 0; k < tape_len; ++k) {
+      unsigned char* b = host.data() + ((size_t)part * tape_len + k) * FleetDirect::kBlockBytes;
+      memcpy(b, L.args, L.args_bytes);
+      const void* row = static_cast<const char*>(tape) + (size_t)k * row_bytes;
+      memcpy(b + L.actions_offset[0], &row, sizeof row);
+      memcpy(b + L.actions_offset[1], &row, sizeof row);
+      if (part == 1) {
+        int32_t packed;
+        memcpy(&packed, b + L.packed_n_offset, 4);
+        packed = (int32_t)(((uint32_t)packed & 0xffffu) | (q->part_grid[0] << 16));
+        memcpy(b + L.packed_n_offset, &packed, 4);
+      }
+    }
   if (hipMemcpy(q->kargs_dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) {
     if (err) *err = "fleet_direct_prepare: argument upload failed";
     return FLEET_ERR_HIP;
@@ -295,50 +330,62 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
 }
 
 int fleet_direct_submit(FleetDirect* q, int steps, bool timed, std::string* err) {
-  if (!q || !q->queue || q->tape_len < 1 || steps < 1) return FLEET_ERR_INVALID;
-  hsa_signal_t first{}, lastsig = take_signal(q);
-  if (timed) first = take_signal(q);
-  if (!lastsig.handle || (timed && !first.handle)) {
-    if (err) *err = "fleet_direct_submit: hsa_signal_create failed";
-    return FLEET_ERR_HIP;
+  if (!q || !q->queue[0] || q->tape_len < 1 || steps < 1) return FLEET_ERR_INVALID;
+  FleetDirect::Mark m{};
+  m.parts = q->parts;
+  for (int part = 0; part < q->parts; ++part) {
+    m.last[part] = take_signal(q);
+    m.first[part] = timed ? take_signal(q) : hsa_signal_t{};
+    if (!m.last[part].handle || (timed && !m.first[part].handle)) {
+      if (err) *err = "fleet_direct_submit: hsa_signal_create failed";
+      return FLEET_ERR_HIP;
+    }
+    q->pending.push_back(m.last[part]);
+    if (timed) q->pending.push_back(m.first[part]);
   }
-  q->pending.push_back(lastsig);
-  if (timed) q->pending.push_back(first);
-  hsa_queue_t* hq = q->queue;
-  const uint32_t mask = hq->size - 1;
-  for (int i = 0; i < steps; ++i) {
-    const uint64_t idx = hsa_queue_add_write_index_relaxed(hq, 1);
-    while (idx - hsa_queue_load_read_index_scacquire(hq) >= hq->size) {}
-    hsa_kernel_dispatch_packet_t* p = static_cast<hsa_kernel_dispatch_packet_t*>(hq->base_address) + (idx & mask);
-    p->workgroup_size_x = (uint16_t)q->block; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
-    p->grid_size_x = q->grid * q->block; p->grid_size_y = 1; p->grid_size_z = 1;
-    p->private_segment_size = q->kernel.scratch_bytes;
-    p->group_segment_size = q->kernel.lds_bytes;
-    p->kernel_object = q->kernel.object;
-    p->kernarg_address = q->kargs_dev + (size_t)(i % q->tape_len) * FleetDirect::kBlockBytes;
-    p->reserved2 = 0;
-    hsa_signal_t none{};
-    p->completion_signal = (i == steps - 1) ? lastsig : ((timed && i == 0) ? first : none);
-    // the first packet of a run acquires at system scope (whatever the host or another queue wrote before the run), the others at
-    // agent scope; only the last one releases
-    const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-    const int rel = (i == steps - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
-    const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                       (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-    const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
-    __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
-    hsa_signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)idx);
+  for (int i = 0; i < steps; ++i)
+    for (int part = 0; part < q->parts; ++part) {  // step by step, queue by queue: both chains get going at once
+      hsa_queue_t* hq = q->queue[part];
+      const uint64_t idx = hsa_queue_add_write_index_relaxed(hq, 1);
+      while (idx - hsa_queue_load_read_index_scacquire(hq) >= hq->size) {}
+      hsa_kernel_dispatch_packet_t* p = static_cast<hsa_kernel_dispatch_packet_t*>(hq->base_address) + (idx & (hq->size - 1));
+      p->workgroup_size_x = (uint16_t)q->block; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
+      p->grid_size_x = q->part_grid[part] * q->block; p->grid_size_y = 1; p->grid_size_z = 1;
+      p->private_segment_size = q->kernel.scratch_bytes;
+      p->group_segment_size = q->kernel.lds_bytes;
+      p->kernel_object = q->kernel.object;
+      p->kernarg_address = q->kargs_dev + ((size_t)part * q->tape_len + (size_t)(i % q->tape_len)) * FleetDirect::kBlockBytes;
+      p->reserved2 = 0;
+      hsa_signal_t none{};
+      p->completion_signal = (i == steps - 1) ? m.last[part] : ((timed && i == 0) ? m.first[part] : none);
+      // the first packet of a run acquires at system scope (whatever the host or another queue wrote before the run), the others at
+      // agent scope; only the last one releases
+      const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+      const int rel = (i == steps - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
+      const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                         (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+      const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+      __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+      hsa_signal_store_screlease(hq->doorbell_signal, (hsa_signal_value_t)idx);
+    }
+  if (timed) {
+    if (steps == 1)  // (one packet cannot carry two signals: its own start and end are the span then)
+      for (int part = 0; part < q->parts; ++part) m.first[part] = m.last[part];
+    q->marks.push_back(m);
   }
-  if (timed) {  // (one packet cannot carry two signals: its own start and end are the span then)
-    q->marks.push_back(steps == 1 ? lastsig : first);
-    q->marks.push_back(lastsig);
-  }
-  q->last = lastsig;
+  for (int part = 0; part < 2; ++part) q->last[part] = part < q->parts ? m.last[part] : hsa_signal_t{};
   q->in_flight = true;
   return FLEET_OK;
 }
 
-bool fleet_direct_busy(FleetDirect* q) { return q && q->in_flight && hsa_signal_load_scacquire(q->last) >= 1; }
+int fleet_direct_parts(FleetDirect* q) { return q ? q->parts : 0; }
+
+bool fleet_direct_busy(FleetDirect* q) {
+  if (!q || !q->in_flight) return false;
+  for (hsa_signal_t sgn : q->last)
+    if (sgn.handle && hsa_signal_load_scacquire(sgn) >= 1) return true;
+  return false;
+}
 
 int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string* err) {
   if (!q) return FLEET_ERR_INVALID;
@@ -347,22 +394,31 @@ int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string
     // synchronises right after a short run wants it back within microseconds), then sleep on the signal's interrupt.
     // 60 s in all: a run of 16384 launches of the largest batch is ~1 s
     const uint64_t hz = q->tick_hz ? q->tick_hz : 100000000ull;
-    if (hsa_signal_wait_scacquire(q->last, HSA_SIGNAL_CONDITION_LT, 1, hz / 1000, HSA_WAIT_STATE_ACTIVE) >= 1 &&
-        hsa_signal_wait_scacquire(q->last, HSA_SIGNAL_CONDITION_LT, 1, hz * 60ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
-      if (err) *err = "fleet_direct_wait: the run did not complete within 60 s";
-      return FLEET_ERR_HIP;
+    for (hsa_signal_t sgn : q->last) {
+      if (!sgn.handle) continue;
+      if (hsa_signal_wait_scacquire(sgn, HSA_SIGNAL_CONDITION_LT, 1, hz / 1000, HSA_WAIT_STATE_ACTIVE) >= 1 &&
+          hsa_signal_wait_scacquire(sgn, HSA_SIGNAL_CONDITION_LT, 1, hz * 60ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
+        if (err) *err = "fleet_direct_wait: the run did not complete within 60 s";
+        return FLEET_ERR_HIP;
+      }
     }
     q->in_flight = false;
   }
-  for (size_t k = 0; k + 1 < q->marks.size(); k += 2) {
-    hsa_amd_profiling_dispatch_time_t a{}, b{};
-    const bool ok = hsa_amd_profiling_get_dispatch_time(q->agent, q->marks[k], &a) == HSA_STATUS_SUCCESS &&
-                    hsa_amd_profiling_get_dispatch_time(q->agent, q->marks[k + 1], &b) == HSA_STATUS_SUCCESS;
-    if (spans_us) spans_us->push_back(ok && q->tick_hz ? (double)(b.end - a.start) * 1e6 / (double)q->tick_hz : -1.0);
+  for (const FleetDirect::Mark& m : q->marks) {  // a timed run: from the earlier start of its first launches to the later end of its last
+    uint64_t t0 = UINT64_MAX, t1 = 0;
+    bool ok = true;
+    for (int part = 0; part < m.parts; ++part) {
+      hsa_amd_profiling_dispatch_time_t a{}, b{};
+      ok = ok && hsa_amd_profiling_get_dispatch_time(q->agent, m.first[part], &a) == HSA_STATUS_SUCCESS &&
+           hsa_amd_profiling_get_dispatch_time(q->agent, m.last[part], &b) == HSA_STATUS_SUCCESS;
+      t0 = a.start < t0 ? a.start : t0;
+      t1 = b.end > t1 ? b.end : t1;
+    }
+    if (spans_us) spans_us->push_back(ok && q->tick_hz && t1 > t0 ? (double)(t1 - t0) * 1e6 / (double)q->tick_hz : -1.0);
   }
   q->marks.clear();
   for (hsa_signal_t sgn : q->pending) q->pool.push_back(sgn);
   q->pending.clear();
-  q->last.handle = 0;
+  q->last[0].handle = q->last[1].handle = 0;
   return FLEET_OK;
 }

@@ -1008,10 +1008,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
   };
   constexpr bool kPol = MULTI && (MODE == kModeAll || MODE == kModePolicy);  // the built-in policies are compiled in
   constexpr bool kRt = MULTI && (MODE == kModeAll || MODE == kModeRt);       // the event-skipping loop is compiled in
-  const int N = p_N, E_ = p_E;
+  // `p_N`: EVs per env in the low half; in the high half the workgroup this launch's grid starts at -- 0 for every launch through HIP;
+  // a run on the library's own queues may cover the batch with two grids on two queues (fleet_direct.hip), and the second grid's
+  // workgroups continue the first one's numbering.  (Here because it is needed before the first load: p_N is a preloaded argument.)
+  const int N = p_N & 0xffff, E_ = p_E;
+  const int wg_base = (int)((unsigned)p_N >> 16);
   const int g = threadIdx.x % G;
   const bool leader = (g == G - 1);
-  int e_raw = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  int e_raw = ((int)blockIdx.x + wg_base) * (kBlock / G) + threadIdx.x / G;
   if (G >= 64) e_raw = __builtin_amdgcn_readfirstlane(e_raw);
   const bool env_ok = e_raw < E_;  // surplus groups of the last block run the arithmetic on env E-1 but store nothing
   const int e = env_ok ? e_raw : E_ - 1;
@@ -1649,6 +1653,7 @@ inline void describe_launch(FleetStepLaunch* L, const void* host_fn, dim3 grid, 
   a.obs = obs; a.reward = reward; a.done = done; a.terminal_obs = terminal_obs; a.done_count = done_count;
   L->host_fn = host_fn; L->grid = grid.x; L->block = block.x; L->args_bytes = (unsigned)sizeof a;
   L->actions_offset[0] = (unsigned)offsetof(StepKernargs, p_actions); L->actions_offset[1] = (unsigned)offsetof(StepKernargs, actions);
+  L->packed_n_offset = (unsigned)offsetof(StepKernargs, p_N);
   memcpy(L->args, &a, sizeof a);
 }
 #define FLEET_LAUNCH_SINGLE(KERNEL, GRID)                                                                                              \

@@ -342,8 +342,14 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
 #define FLEET_LAUNCH_EAGER 0
 #define FLEET_LAUNCH_GRAPH 1
 #define FLEET_LAUNCH_DIRECT 2
+/* FLEET_LAUNCH_DIRECT covers a batch of more wavefronts than the device holds at once (>= 6144, envs of up to 64 EVs) with two
+ * ranges of workgroups on TWO queues, each an in-order chain of its own (the halves drift apart and overlap: 16384 x 50 -17 % per
+ * step); FLEET_LAUNCH_DIRECT_ONE_QUEUE never does.  fleet_direct_queues: how the handle's last direct run was laid out (0: none yet). */
+#define FLEET_LAUNCH_DIRECT_ONE_QUEUE 3
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
+
+int fleet_direct_queues(fleet_handle h);
 
 /* `regions` timed regions of exactly `steps` launches each (as fleet_run_tape_dev), enqueued back to back on the handle's stream
  * with a HIP event before and after each: the kernels' own time per region, without the host's gaps between regions.

@@ -154,3 +154,40 @@ def test_direct_float64_tape_and_two_handles_in_flight():
             np.testing.assert_array_equal(y.get(f), x.get(f), err_msg=f)
     for x in (a, b, c, d):
         x.close()
+
+
+def test_large_batch_runs_on_two_queues_bit_identically():
+    """6400 envs x 50 EVs = 6400 wavefronts per launch: FLEET_LAUNCH_DIRECT covers the grid with two ranges of workgroups on two queues
+    (the second range's workgroups continue the first one's numbering); the result is that of the stream launches and of one queue."""
+    from fleetrl_amd.batch import FleetBatch
+    from fleetrl_amd.config import resolve_config
+    from fleetrl_amd.params import make_params, time_features
+    from test_hip_shapes import _cfg, _tables
+    import torch
+
+    E, N = 6400, 50
+    tb = _tables("ct", N)
+    p = make_params(resolve_config(_cfg("ct", "rainflow", False, episode_length=24)), tb, E, seed=3)
+    tf = time_features(tb)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, size=(9, E, N)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tape = torch.from_numpy(acts).to(dev)
+    runs = []
+    for mode in (_capi.LAUNCH_EAGER, _capi.LAUNCH_DIRECT, _capi.LAUNCH_DIRECT_ONE_QUEUE):
+        b = FleetBatch(p, tb, tf)
+        o = (torch.zeros((E, b.obs_dim), device=dev), torch.zeros(E, device=dev, dtype=torch.float64), torch.zeros(E, device=dev, dtype=torch.uint8))
+        b.reset_dev(o[0].data_ptr())
+        for steps in (5, 130):
+            b.run_tape_dev(steps, tape.data_ptr(), 9, *(t.data_ptr() for t in o), use_graph=mode)
+        b.synchronize()
+        runs.append((b, o))
+    assert runs[1][0].direct_queues() == 2 and runs[2][0].direct_queues() == 1
+    for b, o in runs[1:]:
+        for k in range(3):
+            np.testing.assert_array_equal(o[k].cpu().numpy(), runs[0][1][k].cpu().numpy())
+        for f in STATE:
+            np.testing.assert_array_equal(b.get(f), runs[0][0].get(f), err_msg=f)
+        b.check_errors()
+    for b, _ in runs:
+        b.close()

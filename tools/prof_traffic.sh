@@ -22,7 +22,7 @@ n_groups = 1
 lines = [l for l in open(f"{out}/bench_fetch.log") if l.startswith("{")]
 if lines:
     j = json.loads(lines[-1])
-    n_groups = len(j["config"]["groups"])
+    n_groups = j["config"].get("launches_per_step", len(j["config"]["groups"]))  # kernels of the single-step instance per step
     res.update(groups=n_groups, envs=j["config"]["envs_per_gpu"], evs=j["config"]["evs_per_env"], config=j["config"]["name"],
                algorithmic_bytes_per_launch=j["roofline"]["bytes_per_launch"], kernel=j["roofline"]["kernel"],
                launch_mode=j["config"].get("launch_mode", "graph"))
