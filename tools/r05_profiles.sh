@@ -18,6 +18,7 @@ python3 bench.py --launch graph --steps 20 --warmup 5 --no-cpu-baseline --no-hos
 python3 bench.py --launch graph --config c4 --no-cpu-baseline --no-host-path > $OUT/r05_bench_c4_graph.json 2>> $OUT/bench.err
 python3 bench.py --launch graph --config c5 --no-cpu-baseline --no-host-path > $OUT/r05_bench_c5_graph.json 2>> $OUT/bench.err
 python3 bench.py --launch graph --envs-per-gpu 16384 --no-cpu-baseline --no-host-path > $OUT/r05_bench_16384x50_graph.json 2>> $OUT/bench.err
+python3 bench.py --launch direct1 --envs-per-gpu 16384 --no-cpu-baseline --no-host-path > $OUT/r05_bench_16384x50_onequeue.json 2>> $OUT/bench.err
 kt() { rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$1 -- python3 bench.py --no-cpu-baseline --no-host-path "${@:2}" > $OUT/kt_$1.log 2>&1; cp $OUT/kt_$1/*/*kernel_stats.csv $OUT/r05_step_kernel_stats_$1.csv; rm -rf $OUT/kt_$1; }
 kt c3
 kt c3_graph --launch graph
