@@ -286,9 +286,8 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
   // range's workgroups continue the numbering of the first (the kernel's packed `p_N`), so env e stays workgroup e / (256 / G) and
   // keeps its die; the first range is a multiple of 8 workgroups.
   q->parts = (split && L.grid >= 16) ? 2 : 1;
+  if (q->parts == 2 && open_queue(q, 1, nullptr) != FLEET_OK) q->parts = 1;  // no second queue to be had: one chain, as for small batches
   if (q->parts == 2) {
-    const int rc = open_queue(q, 1, err);
-    if (rc != FLEET_OK) return rc;
     q->part_grid[0] = ((L.grid / 2 + 7) / 8) * 8;
     q->part_grid[1] = L.grid - q->part_grid[0];
   } else {
@@ -331,6 +330,10 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
 
 int fleet_direct_submit(FleetDirect* q, int steps, bool timed, std::string* err) {
   if (!q || !q->queue[0] || q->tape_len < 1 || steps < 1) return FLEET_ERR_INVALID;
+  if (q->pending.size() > 4096) {  // a caller that submits run after run without ever waiting (more than any timed series: <= 256 regions): a wait recycles the signals
+    const int rc = fleet_direct_wait(q, nullptr, err);
+    if (rc != FLEET_OK) return rc;
+  }
   FleetDirect::Mark m{};
   m.parts = q->parts;
   for (int part = 0; part < q->parts; ++part) {
