@@ -191,3 +191,41 @@ def test_large_batch_runs_on_two_queues_bit_identically():
         b.check_errors()
     for b, _ in runs:
         b.close()
+
+
+@pytest.mark.parametrize("E,steps,queues", [(4096, 2500, 1), (16384, 700, 2)])
+def test_direct_long_run_at_the_bench_shapes(E, steps, queues):
+    """The headline batch (4096 x 50, one queue) over 13 episodes and the 16384 x 50 batch (two queues) over 3: the state the library's
+    own launches leave is the stream launches' state, word for word -- every env, every EV, the rainflow counts and the SoH included."""
+    from fleetrl_amd.batch import FleetBatch
+    from fleetrl_amd.config import resolve_config
+    from fleetrl_amd.params import make_params, time_features
+    from fleetrl_amd.synth import synth_tables
+    from bench import bench_config
+    import torch
+
+    N = 50
+    tb = synth_tables("ct", N)
+    p = make_params(resolve_config(bench_config(E, N, "ct")), tb, E, seed=0)
+    tf = time_features(tb)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    tape = torch.rand((8, E, N), device=dev, generator=gen) * 2 - 1
+    tape[torch.rand((8, E, N), device=dev, generator=gen) < 0.15] = 0.0
+    out = []
+    for mode in (_capi.LAUNCH_GRAPH, _capi.LAUNCH_DIRECT):
+        b = FleetBatch(p, tb, tf)
+        o = (torch.zeros((E, b.obs_dim), device=dev), torch.zeros(E, device=dev, dtype=torch.float64), torch.zeros(E, device=dev, dtype=torch.uint8))
+        b.reset_dev(o[0].data_ptr())
+        b.run_tape_dev(steps, tape.data_ptr(), 8, *(t.data_ptr() for t in o), use_graph=mode)
+        b.synchronize()
+        out.append((b, o))
+    assert out[1][0].direct_queues() == queues
+    for k in range(3):
+        np.testing.assert_array_equal(out[1][1][k].cpu().numpy(), out[0][1][k].cpu().numpy())
+    for f in STATE + ("sei_l", "cashflow"):
+        np.testing.assert_array_equal(out[1][0].get(f), out[0][0].get(f), err_msg=f)
+    assert out[0][0].get("episodes").min() >= steps // 192
+    for b, _ in out:
+        b.check_errors()
+        b.close()
