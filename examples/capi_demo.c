@@ -7,7 +7,8 @@
  * tables.bin: the FleetTables columns back to back in declaration order (there u8[T*N], time_left f32[T*N],
  *             soc_on_return f64[T*N], delu/tariff/prc/trc/load/pv f64[T] each, hour/minute/month/weekday u8[T] each).
  * Drives `steps` steps with a fixed action pattern and prints the sum of rewards, the number of finished episodes and the
- * final SOC sum -- the same numbers the test computes through the Python front end.
+ * final SOC sum -- the same numbers the test computes through the Python front end.  With -DFLEET_DEMO_DEVICE_TAPE (see below) it
+ * also replays a device-resident action tape through HIP launches and through the library's own queue and compares the results.
  */
 #include <math.h>
 #include <stdio.h>
@@ -15,6 +16,9 @@
 #include <string.h>
 
 #include "fleet_hip.h"
+#ifdef FLEET_DEMO_DEVICE_TAPE
+#include <hip/hip_runtime_api.h>
+#endif
 
 static void* slurp(const char* path, size_t* len) {
   FILE* f = fopen(path, "rb");
@@ -78,5 +82,37 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < E * N; ++i) soc_sum += soc[i];
   printf("%.17g %ld %.17g %d\n", reward_sum, episodes, soc_sum, D);
   fleet_destroy(h);
+
+#ifdef FLEET_DEMO_DEVICE_TAPE
+  /* Device-pointer entry points, still without PyTorch: two handles from the same parameters replay one recorded action tape of
+   * `steps` steps -- one through HIP launches, one through the library's own AQL queue (FLEET_LAUNCH_DIRECT) -- and must end in the
+   * same state, bit for bit.  (Needs the HIP runtime for the device buffers: build with -DFLEET_DEMO_DEVICE_TAPE
+   * -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -lamdhip64.) */
+  {
+    const int L = 16;
+    float* tape_h = (float*)malloc((size_t)L * E * N * sizeof(float));
+    for (size_t i = 0; i < (size_t)L * E * N; ++i) tape_h[i] = (float)(((int)((i * 11) % 23) - 9) / 13.0);
+    double* soc2[2];
+    int queues = -1;
+    for (int mode = 0; mode < 2; ++mode) {
+      fleet_handle g = NULL;
+      void *tape_d, *obs_d, *rew_d, *done_d;
+      if (fleet_create(p, &t, 0, &g) != FLEET_OK) { fprintf(stderr, "fleet_create: %s\n", fleet_last_error(NULL)); return 1; }
+      if (hipMalloc(&tape_d, (size_t)L * E * N * 4) != hipSuccess || hipMalloc(&obs_d, E * (size_t)D * 4) != hipSuccess ||
+          hipMalloc(&rew_d, E * 8) != hipSuccess || hipMalloc(&done_d, E) != hipSuccess ||
+          hipMemcpy(tape_d, tape_h, (size_t)L * E * N * 4, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "hipMalloc\n"); return 1; }
+      if (fleet_reset_dev(g, NULL, (float*)obs_d) != FLEET_OK ||
+          fleet_run_tape_dev(g, steps, tape_d, L, FLEET_ACT_F32, (float*)obs_d, (double*)rew_d, (unsigned char*)done_d,
+                             mode ? FLEET_LAUNCH_DIRECT : FLEET_LAUNCH_EAGER) != FLEET_OK ||
+          fleet_synchronize(g) != FLEET_OK) { fprintf(stderr, "tape run (%d): %s\n", mode, fleet_last_error(g)); return 1; }
+      if (mode) queues = fleet_direct_queues(g);
+      soc2[mode] = (double*)malloc(E * N * sizeof(double));
+      if (fleet_get(g, FLEET_F_SOC, soc2[mode]) != FLEET_OK || fleet_check_errors(g) != FLEET_OK) { fprintf(stderr, "get: %s\n", fleet_last_error(g)); return 1; }
+      fleet_destroy(g);
+      hipFree(tape_d); hipFree(obs_d); hipFree(rew_d); hipFree(done_d);
+    }
+    printf("direct_queue_matches %d queues %d\n", memcmp(soc2[0], soc2[1], E * N * sizeof(double)) == 0, queues);
+  }
+#endif
   return 0;
 }

@@ -251,8 +251,10 @@ def test_c_abi_from_plain_c(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib_dir = os.path.dirname(build.lib_path())
     exe = str(tmp_path / "capi_demo")
-    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "capi_demo.c"), "-o", exe,
-                    "-L", lib_dir, "-l:libfleet_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
+    subprocess.run(["gcc", "-O1", "-DFLEET_DEMO_DEVICE_TAPE", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                    "-I", os.path.join(root, "include"), os.path.join(root, "examples", "capi_demo.c"), "-o", exe,
+                    "-L", lib_dir, "-l:libfleet_hip.so", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-lm"], check=True)
     g = load_trace("ct5_both_rainflow")
     E, steps = 11, 230
     p = params_for(g, num_envs=E)
@@ -267,6 +269,9 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe, str(tmp_path / "params.bin"), str(tmp_path / "tables.bin"), str(steps)], check=True,
                          capture_output=True, text=True).stdout.split()
     c_reward, c_episodes, c_soc, c_dim = float(out[0]), int(out[1]), float(out[2]), int(out[3])
+    # ... and, in that process (the system's HIP and HSA runtimes, no PyTorch), the same action tape through HIP launches and through
+    # the library's own queue: the same final state
+    assert out[4:] == ["direct_queue_matches", "1", "queues", "1"], out[4:]
 
     hip = FleetBatch(p, tb, None)  # time features computed by the library, as in the C program
     hip.reset()
