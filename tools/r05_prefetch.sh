@@ -1,0 +1,7 @@
+# usage (GPU box): bash tools/r05_prefetch.sh -- parity of the tape replays, then bench lines of both launch paths at the main shapes
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+timeout 900 python3 -m pytest tests/test_direct_gpu.py tests/test_capi_gpu.py tests/test_hip_shapes.py -q -m gpu -x 2>&1 | tail -4
+for rep in 1 2; do for L in direct graph; do for A in "" "--steps 20 --warmup 5" "--config c4" "--envs-per-gpu 16384" "--config c5"; do
+python3 bench.py --launch $L $A --no-cpu-baseline --no-host-path 2>/dev/null | tail -1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$L $A ms/step %.4f kernel_ms %.4f frac %.3f value %.3e'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['value']))"
+done; done; done | tee gpurun_out/r05/next_row_prefetch.log
