@@ -218,6 +218,9 @@ def load_library():
     if hasattr(lib, "fleet_direct_queues"):  # (absent from older libraries the A/B scripts run beside the tree's)
         lib.fleet_direct_queues.argtypes = [vp]
         lib.fleet_direct_queues.restype = C.c_int
+    if hasattr(lib, "fleet_selftest_stress"):
+        lib.fleet_selftest_stress.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
+        lib.fleet_selftest_stress.restype = C.c_int
     if hasattr(lib, "fleet_selftest_division"):  # (absent from the round-4 library the A/B scripts run beside the tree's)
         lib.fleet_selftest_division.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         lib.fleet_selftest_division.restype = C.c_int
@@ -244,5 +247,5 @@ EXPORTED_SYMBOLS = (
     "fleet_timer_stop", "fleet_timer_mark", "fleet_timer_read", "fleet_run_tape_dev", "fleet_time_steps_dev",
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
-    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues",
+    "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues", "fleet_selftest_stress",
 )

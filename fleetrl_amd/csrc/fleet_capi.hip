@@ -1385,6 +1385,24 @@ int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_l
 
 }  // extern "C"
 
+int fleet_selftest_stress(int device, uint64_t n_samples, uint64_t seed, double* max_rel_err) {
+  if (!max_rel_err || n_samples == 0) return FLEET_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLEET_ERR_NODEVICE;
+  if (device < 0 || device >= ndev) return FLEET_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return FLEET_ERR_HIP;
+  unsigned long long* worst = nullptr;
+  if (hipMalloc(&worst, sizeof(unsigned long long)) != hipSuccess) return FLEET_ERR_HIP;
+  int rc = FLEET_OK;
+  unsigned long long host = 0;
+  if (hipMemset(worst, 0, sizeof host) != hipSuccess || fleet_launch_selftest_stress(n_samples, seed, worst, nullptr) != hipSuccess ||
+      hipMemcpy(&host, worst, sizeof host, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = FLEET_ERR_HIP;
+  (void)hipFree(worst);
+  memcpy(max_rel_err, &host, sizeof host);
+  return rc;
+}
+
 int fleet_selftest_division(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches) {
   if (!mismatches || n_pairs == 0) return FLEET_ERR_INVALID;
   int ndev = 0;

@@ -266,4 +266,6 @@ hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t 
 // unpack state planes for fleet_get: field ids of include/fleet_hip.h -> contiguous device buffer `out`
 hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s);
 // div_rcp (the charge arithmetic's divisions by a reciprocal) against the IEEE sequence on n random operand pairs: bad_dev[0..1]
+// cycle_stress against library double precision on n random triples: worst_dev[0] = bits of the largest relative difference
+hipError_t fleet_launch_selftest_stress(unsigned long long n, unsigned long long seed, unsigned long long* worst_dev, hipStream_t s);
 hipError_t fleet_launch_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long* bad_dev, hipStream_t s);

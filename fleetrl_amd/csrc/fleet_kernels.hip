@@ -1621,6 +1621,28 @@ __global__ void fleet_selftest_division_kernel(unsigned long long n, unsigned lo
   if (b1) atomicAdd(bad + 1, b1);
 }
 
+// cycle_stress (hardware float32 log2 inside x^-0.501, Taylor exp) against the same expression in library double precision, on n
+// pseudo-random (range, mean, weight) triples of the reachable domain: worst[0] = largest relative difference as the bits of a double
+__global__ void fleet_selftest_stress_kernel(unsigned long long n, unsigned long long seed, unsigned long long* __restrict__ worst) {
+  double w = 0.0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long h = mix64(seed + i * 3ull);
+    // depth of discharge: half of the samples log-uniform over 1e-9 ... 1 (tiny cycles are the common ones), half uniform
+    const double u = u01(h), v = u01(mix64(h + 1));
+    const double rng = (h & 1) ? exp(-20.7232658 * u) : u;
+    const double mean = -0.25 + 1.5 * v;  // a mean SOC a little outside [0, 1] too (quirk Q9: the reference does not clip it)
+    const double count = (h & 2) ? 1.0 : 0.5;
+    const double st = 0.9 + 0.2 * u01(mix64(h + 2));
+    const double got = cycle_stress(rng, mean, count, st);
+    double eff = rng * count;
+    eff = eff > 1.0 ? 1.0 : eff;
+    const double want = (eff > 0.0) ? (1.0 / (1.4E5 * pow(eff, -0.501) + -1.23E5)) * exp(1.04 * (mean - 0.5)) * st : 0.0;
+    const double rel = (want != 0.0) ? fabs(got - want) / fabs(want) : fabs(got);
+    w = rel > w ? rel : w;
+  }
+  atomicMax(worst, (unsigned long long)__double_as_longlong(w));  // non-negative doubles order like their bit patterns
+}
+
 int group_size(int N) {
   int G = 1;
   while (G < N && G < 64) G <<= 1;
@@ -1790,6 +1812,11 @@ hipError_t fleet_launch_dist_factor(const FleetDev& d, double* out, hipStream_t 
 hipError_t fleet_launch_gather_field(const FleetDev& d, int field, void* out, hipStream_t s) {
   const size_t n = (size_t)d.E * d.N;
   hipLaunchKernelGGL(fleet_gather_field_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, field, out);
+  return hipGetLastError();
+}
+
+hipError_t fleet_launch_selftest_stress(unsigned long long n, unsigned long long seed, unsigned long long* worst_dev, hipStream_t s) {
+  hipLaunchKernelGGL(fleet_selftest_stress_kernel, dim3(2048), dim3(256), 0, s, n, seed, worst_dev);
   return hipGetLastError();
 }
 

@@ -371,6 +371,12 @@ int fleet_time_steps_dev(fleet_handle h, int steps, const void* tape, int tape_l
  * forms on `n_pairs` pseudo-random operand pairs of the charge arithmetic's ranges on the device and returns how many quotients
  * differ in any bit: mismatches[0] for `need / eta_c`, mismatches[1] for `energy / cap` (expected: 0 and 0). */
 int fleet_selftest_division(int device, uint64_t n_pairs, uint64_t seed, uint64_t* mismatches);
+/* The stress of a closed rainflow cycle (deg_rate_cycle, rainflow_sei_degradation.py:68-80: (kd1 * dod^kd2 + kd3)^-1 * e^(k_sigma *
+ * (soc - sigma_ref)) * stress_temp) is evaluated with a hardware float32 logarithm inside dod^-0.501 and polynomial exponentials instead
+ * of the library's pow / exp.  This entry evaluates both forms on `n_samples` pseudo-random (depth of discharge, mean SOC, cycle weight)
+ * triples of the reachable domain on the device and returns the largest relative difference (expected: < 1e-8; the degradation it
+ * feeds is a 1e-5-sized correction to the state of health). */
+int fleet_selftest_stress(int device, uint64_t n_samples, uint64_t seed, double* max_rel_err);
 
 #ifdef __cplusplus
 }

@@ -291,6 +291,19 @@ def test_c_abi_from_plain_c(tmp_path):
     assert c_soc == soc_sum
 
 
+def test_cycle_stress_stays_within_its_stated_accuracy():
+    """the stress of a closed cycle uses a float32 hardware logarithm and polynomial exponentials inside a float64
+    path.  On 2^27 samples of the reachable (depth of discharge, mean SOC, weight) domain the kernel's form stays within 1e-8 relative of
+    the library's pow / exp (the docs say <= 4e-9 from the logarithm alone); SoH moves by 1e-5 per day, so that is 1e-13 of SoH."""
+    import ctypes as C
+
+    lib = _capi.load_library()
+    worst = C.c_double(-1.0)
+    for seed in (1, 99):
+        assert lib.fleet_selftest_stress(0, 1 << 27, seed, C.byref(worst)) == _capi.OK
+        assert 0.0 <= worst.value < 1e-8, worst.value
+
+
 def test_rccl_gather_of_episode_stats_through_the_c_abi():
     """SURVEY.md section 8e / north star: "a single RCCL gather of episode returns for logging".  The C ABI does it without
     PyTorch's collectives: fleet_rccl_unique_id / fleet_rccl_comm_create (ncclCommInitRank) / fleet_gather_episode_stats_rccl (one
