@@ -1,10 +1,11 @@
-// Direct AQL submission: a run of single-step launches written into an HSA queue by the library itself (host code only).
+// Direct AQL submission: a run of single-step launches written into HSA queues (one, or two for large batches) by the library itself
+// (host code only).
 //
 // Why: HIP gives every kernel packet an agent-scope acquire AND release fence.  On a part whose eight dies have an L2 each, not
 // coherent with one another, the release is a write-back of the die's dirty lines at the end of EVERY launch -- the next launch waits
-// for it to drain and then fetches its state from beyond the L2 again.  Between two steps of the same batch none of that is needed: workgroup w -- and the
-// hardware hands workgroup w of a grid to die w mod 8 -- owns the same envs in every launch, so every byte of state a die reads was
-// last written by itself (or by nobody: tables, actions).  A run submitted here keeps the acquire (the per-CU vector caches and the
+// for it to drain and then fetches those lines again.  Between two steps of the same batch none of that is needed: workgroup w -- and
+// the hardware hands workgroup w of a grid to die w mod 8 -- owns the same envs in every launch, so every byte of state a die reads
+// was last written by itself (or by nobody: tables, actions).  A run submitted here keeps the acquire (the per-CU vector caches and the
 // scalar caches ARE invalidated at every launch: a wavefront of env e runs on another CU of its die next time) and drops the release
 // on all packets but the last, which releases at system scope: after the run every result is where any reader expects it.
 // tools/ubench/aql_fence.cpp is the microbenchmark of the effect (read-modify-write of 16 MB by 4096 workgroups: 5.3 -> 2.9 us per
