@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
     ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--launch", choices=("graph", "eager", "direct", "direct1"), default="direct",
+    ap.add_argument("--launch", choices=("graph", "eager", "direct", "direct1", "publish"), default="direct",
                     help="how the K launches of a region reach the GPU: a replayed hipGraph (eager below 64 steps), one hipLaunchKernel "
                          "each, or AQL packets written by the library into a queue of its own without the L2 write-back HIP attaches "
                          "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT; a batch of >= 6144 wavefronts goes to two queues, "
@@ -297,7 +297,7 @@ def main():
     launch_mode = "eager" if args.no_graph else args.launch
     if launch_mode == "graph" and args.steps < 64:
         launch_mode = "eager"
-    use_graph = {"eager": 0, "graph": 1, "direct": 2, "direct1": 3}[launch_mode]  # _capi.LAUNCH_*
+    use_graph = {"eager": 0, "graph": 1, "direct": 2, "direct1": 3, "publish": 4}[launch_mode]  # _capi.LAUNCH_*
     launch_note = ""
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):

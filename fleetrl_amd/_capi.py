@@ -11,17 +11,17 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
-OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE = 0, 1, 2, 3, 4
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
 PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
 # fleet_run_tape_dev / fleet_time_regions_begin: how the launches reach the GPU (include/fleet_hip.h FLEET_LAUNCH_*)
-LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT, LAUNCH_DIRECT_ONE_QUEUE = 0, 1, 2, 3
+LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT, LAUNCH_DIRECT_ONE_QUEUE, LAUNCH_DIRECT_PUBLISH = 0, 1, 2, 3, 4
 POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
-DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL = 1, 2, 4, 8, 16, 32
+DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL, DEVERR_PLACEMENT = 1, 2, 4, 8, 16, 32, 64
 
 # fleet_get fields: name -> (id, dtype, per_car)
 FIELDS = {
@@ -218,6 +218,14 @@ def load_library():
     if hasattr(lib, "fleet_direct_queues"):  # (absent from older libraries the A/B scripts run beside the tree's)
         lib.fleet_direct_queues.argtypes = [vp]
         lib.fleet_direct_queues.restype = C.c_int
+    if hasattr(lib, "fleet_step_direct_dev"):  # (ABI 9; absent from older libraries the A/B scripts run beside the tree's)
+        lib.fleet_step_direct_dev.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
+        lib.fleet_wait_step.argtypes = [vp]
+        lib.fleet_direct_placement.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.fleet_direct_split_plan.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+        lib.fleet_debug_direct_fault.argtypes = [vp, C.c_int, C.c_int]
+        for name in ("fleet_step_direct_dev", "fleet_wait_step", "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault"):
+            getattr(lib, name).restype = C.c_int
     if hasattr(lib, "fleet_selftest_stress"):
         lib.fleet_selftest_stress.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
         lib.fleet_selftest_stress.restype = C.c_int
@@ -248,4 +256,5 @@ EXPORTED_SYMBOLS = (
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
     "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues", "fleet_selftest_stress",
+    "fleet_step_direct_dev", "fleet_wait_step", "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault",
 )

@@ -103,7 +103,10 @@ class FleetBatch:
         e = int(np.flatnonzero(bits_all)[0])
         bits = int(bits_all[e])
         where = f"env {e} (global env {e + int(self.params.env_id_offset)}), table row {int(rows[e])} of {int(self.params.table_rows)}"
-        if bits & _capi.DEVERR_INTERNAL:
+        if bits & _capi.DEVERR_PLACEMENT:
+            exc = FleetHipError(_capi.ERR_STATE, "a launch on the library's own queue ran a workgroup on another die than the queue's placement "
+                                                 f"probe says (FLEET_DEVERR_PLACEMENT): the run's results are void: {where}")
+        elif bits & _capi.DEVERR_INTERNAL:
             exc = FleetHipError(_capi.ERR_STATE, f"internal error of the library (inconsistent launch arguments): {where}")
         elif bits & _capi.DEVERR_OBS_FORMAT:
             exc = TypeError("Observation format not recognized")
@@ -299,6 +302,28 @@ class FleetBatch:
                      use_graph: bool = True, act_dtype: int = _capi.ACT_F32):
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
                                                  reward_ptr, done_ptr, int(use_graph)))
+
+    def step_direct_dev(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, terminal_ptr: int | None = None,
+                        act_dtype: int = _capi.ACT_F32):
+        """One step through the library's own queue, closed loop (fleet_step_direct_dev): no release fence -- the state stays in the
+        dies' L2s --, observations / rewards / done flags stored write-through.  Asynchronous; `wait_step()` before anybody reads
+        the outputs.  Every other call on the batch writes the state back first, so the calls mix freely."""
+        self._check(self.lib.fleet_step_direct_dev(self.h, actions_ptr, act_dtype, obs_ptr, reward_ptr, done_ptr, terminal_ptr))
+
+    def wait_step(self):
+        """Host wait for the steps submitted with `step_direct_dev`: their outputs are visible to every stream and to copies."""
+        self._check(self.lib.fleet_wait_step(self.h))
+
+    def direct_placement(self):
+        """(map8, num_xcc, any_grid): the workgroup -> die map the batch's own queue was probed to have (fleet_direct_placement)."""
+        m = (C.c_int32 * 8)()
+        nx, ag = C.c_int32(), C.c_int32()
+        self._check(self.lib.fleet_direct_placement(self.h, m, C.byref(nx), C.byref(ag)))
+        return [int(x) for x in m], int(nx.value), bool(ag.value)
+
+    def debug_direct_fault(self, kind: int, tape_row: int):
+        """TEST HOOK: corrupt the prepared argument block of one tape row (fleet_debug_direct_fault)."""
+        self._check(self.lib.fleet_debug_direct_fault(self.h, int(kind), int(tape_row)))
 
     def direct_queues(self) -> int:
         """How the handle's last direct run (use_graph=_capi.LAUNCH_DIRECT) was laid out: 0 none yet, 1 one queue, 2 two queues."""

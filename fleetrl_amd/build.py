@@ -36,11 +36,26 @@ def code_object_path(lib: str | None = None) -> str:
     return (lib[:-3] if lib.endswith(".so") else lib) + ".gfx950.hsaco"
 
 
+def source_sha(extra_flags=()) -> str:
+    """Identifies what a library and the code object beside it were compiled from: hash of every source and header plus the flags.
+    Both artefacts carry it (`FLEET_SRC_SHA`: a host-side string in the library, a `__device__` symbol in the code object) and
+    fleet_direct_open refuses a code object that is not the library's twin."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join([*FLAGS, *extra_flags]).encode())
+    return h.hexdigest()[:24]
+
+
 def _compile(out_so: str, out_co: str, extra_flags=()) -> list:
     """Both artefacts, side by side (two hipcc processes); returns the command lines.  Raises with the compiler's message."""
     csrc = os.path.join(_HERE, "csrc")
-    cmds = [[hipcc(), *FLAGS, *extra_flags, *[os.path.join(csrc, s) for s in SOURCES], *LINK, "-o", out_so],
-            [hipcc(), *GENCO, *extra_flags, os.path.join(csrc, "fleet_kernels.hip"), "-o", out_co]]
+    sha = f'-DFLEET_SRC_SHA="{source_sha(extra_flags)}"'
+    cmds = [[hipcc(), *FLAGS, *extra_flags, sha, *[os.path.join(csrc, s) for s in SOURCES], *LINK, "-o", out_so],
+            [hipcc(), *GENCO, *extra_flags, sha, os.path.join(csrc, "fleet_kernels.hip"), "-o", out_co]]
     procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for c in cmds]
     outs = [p.communicate() for p in procs]
     for p, (_, err) in zip(procs, outs):

@@ -130,16 +130,24 @@ struct Batch {
   const void* dq_tape = nullptr;
   int dq_len = 0, dq_dtype = 0, dq_mode = 0;
   float* dq_obs = nullptr;
+  float* dq_term = nullptr;
   double* dq_reward = nullptr;
   uint8_t* dq_done = nullptr;
-  bool dq_timed = false;
+  bool dq_publish = false;  // the prepared launch is the instance that stores its outputs write-through (closed-loop steps)
+  uint64_t dq_gen = 0;   // the handle's generation the prepared argument blocks were made in
+  int dq_timed = 0;      // 0 / 1 (first and last packet of a run) / 2 (every packet): fleet_direct_submit
   std::vector<double> dq_spans_us;
+  // Every call that changes what a launch's argument block embeds (the handle's streams, its start schedule, its policy parameters:
+  // anything a later version may move into FleetDev) bumps the generation: argument blocks prepared before it are never reused.
+  uint64_t gen = 1;
 };
 
 // A run submitted to the handle's own queue is not on its HIP stream: every entry point that touches the handle waits for it first.
+// ... and, if its launches left state in the dies' L2s (no release fence between steps), has that written back: whatever the entry
+// point then launches on the HIP stream -- on any die -- or copies to the host reads what the run wrote.
 static int direct_drain(Batch* h) {
   if (!h || !h->direct) return FLEET_OK;
-  return fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error);
+  return fleet_direct_release(h->direct, &h->dq_spans_us, &h->error);
 }
 #define FLEET_ENTER(h)                          \
   do {                                          \
@@ -576,7 +584,9 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
 // Name the first env that carries device error bits (the reference raises at the offending line: fleet_environment.py:610,
 // rainflow_sei_degradation.py:164-167,179-180,209-210; running off the table is a KeyError of its `db.loc[...]`).
 const char* deverr_names(uint32_t bits, char* buf, size_t n) {
-  snprintf(buf, n, "%s%s%s%s%s%s", (bits & FLEET_DEVERR_INTERNAL) ? " internal: inconsistent launch arguments;" : "",
+  snprintf(buf, n, "%s%s%s%s%s%s%s",
+           (bits & FLEET_DEVERR_PLACEMENT) ? " placement: a workgroup of a run on the library's own queue ran on another die than probed, the run's results are void;" : "",
+           (bits & FLEET_DEVERR_INTERNAL) ? " internal: inconsistent launch arguments;" : "",
            (bits & FLEET_DEVERR_OBS_FORMAT) ? " observation format not recognized;" : "",
            (bits & FLEET_DEVERR_NEG_LIFE) ? " life degradation is negative;" : "",
            (bits & FLEET_DEVERR_SOH_MISMATCH) ? " degradation calculation is not correct;" : "",
@@ -695,6 +705,7 @@ const char* fleet_last_error(fleet_handle h) { return h ? h->error.c_str() : g_c
 int fleet_set_stream(fleet_handle h, void* hip_stream) {
   FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
+  h->gen += 1;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // what was enqueued on the stream in use so far is finished before the switch
   drop_graph(h);
@@ -707,6 +718,7 @@ int fleet_set_stream(fleet_handle h, void* hip_stream) {
 int fleet_use_own_stream(fleet_handle h) {
   FLEET_ENTER(h);
   if (!h) return FLEET_ERR_INVALID;
+  h->gen += 1;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drop_graph(h);
@@ -737,6 +749,7 @@ int fleet_stream_query(fleet_handle h) {
 int fleet_set_start_schedule(fleet_handle h, const int32_t* starts, int n_episodes) {
   FLEET_ENTER(h);
   if (!h || n_episodes < 0 || (n_episodes > 0 && !starts)) return FLEET_ERR_INVALID;
+  h->gen += 1;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (h->dev_sched) {
@@ -813,6 +826,7 @@ int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minut
     h->error = "fleet_set_night_policy: argument out of range";
     return FLEET_ERR_INVALID;
   }
+  h->gen += 1;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->cold_host.night_hour = charging_hour;
@@ -1175,7 +1189,7 @@ int fleet_check_errors(fleet_handle h) {
     if (e[i]) {
       std::vector<int32_t> t(h->d.E);
       (void)fleet_get(h, FLEET_F_TIME_IDX, t.data());
-      char names[200], buf[400];
+      char names[400], buf[640];
       snprintf(buf, sizeof buf, "device error bits 0x%x on env %d at table row %d of %d:%s (FLEET_DEVERR_* in fleet_hip.h)", e[i], i, t[i],
                h->d.T, deverr_names(e[i], names, sizeof names));
       h->error = buf;
@@ -1215,6 +1229,61 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms) {
   return FLEET_OK;
 }
 
+// What every submission to the library's own queues has in common: the queue exists (opened at the first use: code object, source
+// hash, placement probe), the launch's argument blocks describe exactly these buffers on the handle as it is now, and everything the
+// HIP stream was given before has completed.  `tape`: tape_len rows of actions (a closed-loop step: one row).
+static int direct_ready(fleet_handle h, const void* tape, int tape_len, int act_dtype, float* obs, double* reward, uint8_t* done,
+                        float* terminal_obs, int mode, bool publish) {
+  if (h->stream != h->own_stream) {
+    // a run is not ordered on a HIP stream: ops queued on a borrowed stream (torch's) after the call would read its outputs too early
+    // and nothing could tell them.  The handle's own stream is never handed to anybody else's ops.
+    h->error = "launches through the library's own queue are not ordered on a borrowed HIP stream: fleet_use_own_stream first "
+               "(the call itself waits for the stream's earlier work; fleet_wait_step / fleet_synchronize order what follows)";
+    return FLEET_ERR_INVALID;
+  }
+  const bool stale = !h->direct || h->dq_gen != h->gen || h->dq_tape != tape || h->dq_len != tape_len || h->dq_dtype != act_dtype ||
+                     h->dq_obs != obs || h->dq_term != terminal_obs || h->dq_reward != reward || h->dq_done != done || h->dq_mode != mode || h->dq_publish != publish;
+  if (stale) {
+    // (the launches in flight read the argument blocks that are about to be replaced)
+    int rc = h->direct ? fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error) : FLEET_OK;
+    if (rc != FLEET_OK) return rc;
+    if (!h->direct) {
+      rc = fleet_direct_open(h->device, &h->direct, &h->error);
+      if (rc != FLEET_OK) return rc;
+    }
+    FleetStepLaunch L;
+    const hipError_t e = fleet_describe_step(h->d, tape, act_dtype, obs, reward, done, terminal_obs, publish, &L);
+    if (e != hipSuccess) {
+      h->error = "direct submission serves single-step launches only (no real_time, no data log)";
+      return FLEET_ERR_INVALID;
+    }
+    // a batch of more wavefronts than are resident at once (256 CUs x 4 SIMDs x 5 of this kernel = 5120) runs as two ranges of
+    // workgroups on two queues; one wavefront per env or less only (the wider groups were not measured to gain)
+#ifndef FLEET_DIRECT_SPLIT_WAVES
+#define FLEET_DIRECT_SPLIT_WAVES 6144
+#endif
+    const bool split = (mode == FLEET_LAUNCH_DIRECT || mode == FLEET_LAUNCH_DIRECT_PUBLISH) && h->d.N <= 64 && (size_t)L.grid * (L.block / 64) >= FLEET_DIRECT_SPLIT_WAVES;
+    // Two layouts of the same batch put the second half of the envs on different queues, and every queue deals its workgroups to the
+    // dies from a die of its own (tools/ubench/xcc_map.cpp): state that the previous layout's launches left in the L2s is written back
+    // before the layout may change
+    if (fleet_direct_dirty(h->direct)) {
+      unsigned pg[2];
+      if (fleet_direct_plan(L.grid, split, pg) != fleet_direct_parts(h->direct) && (rc = fleet_direct_release(h->direct, &h->dq_spans_us, &h->error)) != FLEET_OK)
+        return rc;
+    }
+    h->dq_tape = nullptr;  // whatever happens below, the old key describes nothing any more
+    h->dq_len = 0;
+    const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
+    rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, split, &h->error);
+    if (rc != FLEET_OK) return rc;
+    h->dq_mode = mode; h->dq_gen = h->gen; h->dq_publish = publish;
+    h->dq_tape = tape; h->dq_len = tape_len; h->dq_dtype = act_dtype; h->dq_obs = obs; h->dq_term = terminal_obs; h->dq_reward = reward; h->dq_done = done;
+  }
+  // what the stream was given before (a reset, a copy of actions ...) has completed before the first packet is written
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return FLEET_OK;
+}
+
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                        double* reward, uint8_t* done, int use_graph) {
   if (!h || steps < 0 || !tape || tape_len < 1 || !obs || !reward || !done ||
@@ -1225,38 +1294,14 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
   const char* base = static_cast<const char*>(tape);
-  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {
-    // the library's own AQL packets: the launches of the run keep their state in the dies' L2s (fleet_direct.hip).  Asynchronous
-    // like the other forms; not on the HIP stream -- the next call on the handle (fleet_synchronize ...) waits for the run.
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE || use_graph == FLEET_LAUNCH_DIRECT_PUBLISH) {
+    // the library's own AQL packets: the launches of the run keep their state in the dies' L2s (fleet_direct.hip), the last one
+    // writes it back.  Asynchronous like the other forms; not on the HIP stream -- the next call on the handle waits for the run.
+    // _PUBLISH: the launches of fleet_step_direct_dev (outputs stored write-through), fed from the tape.
     if (steps == 0) return FLEET_OK;
-    const bool stale = !h->direct || h->dq_tape != tape || h->dq_len != tape_len || h->dq_dtype != act_dtype || h->dq_obs != obs ||
-                       h->dq_reward != reward || h->dq_done != done || h->dq_mode != use_graph;
-    if (stale) {
-      FLEET_ENTER(h);
-      if (!h->direct) {
-        const int rc = fleet_direct_open(h->device, &h->direct, &h->error);
-        if (rc != FLEET_OK) return rc;
-      }
-      FleetStepLaunch L;
-      const hipError_t e = fleet_describe_step(h->d, tape, act_dtype, obs, reward, done, nullptr, &L);
-      if (e != hipSuccess) {
-        h->error = "fleet_run_tape_dev: direct submission serves single-step launches only (no real_time, no data log)";
-        return FLEET_ERR_INVALID;
-      }
-      // a batch of more wavefronts than are resident at once (256 CUs x 4 SIMDs x 5 of this kernel = 5120) runs as two ranges of
-      // workgroups on two queues; one wavefront per env or less only (the wider groups were not measured to gain)
-#ifndef FLEET_DIRECT_SPLIT_WAVES
-#define FLEET_DIRECT_SPLIT_WAVES 6144
-#endif
-      const bool split = use_graph == FLEET_LAUNCH_DIRECT && h->d.N <= 64 && (size_t)L.grid * (L.block / 64) >= FLEET_DIRECT_SPLIT_WAVES;
-      const int rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, split, &h->error);
-      if (rc != FLEET_OK) return rc;
-      h->dq_mode = use_graph;
-      h->dq_tape = tape; h->dq_len = tape_len; h->dq_dtype = act_dtype; h->dq_obs = obs; h->dq_reward = reward; h->dq_done = done;
-    }
-    // what the stream was given before the run (a reset, a copy of actions ...) has completed before its first packet is written
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return fleet_direct_submit(h->direct, steps, h->dq_timed, &h->error);
+    const int rc = direct_ready(h, tape, tape_len, act_dtype, obs, reward, done, nullptr, use_graph, use_graph == FLEET_LAUNCH_DIRECT_PUBLISH);
+    if (rc != FLEET_OK) return rc;
+    return fleet_direct_submit(h->direct, steps, h->dq_timed, /*release_last=*/true, &h->error);
   }
   FLEET_ENTER(h);
   int i = 0;
@@ -1307,17 +1352,70 @@ int fleet_direct_queues(fleet_handle h) {
   return h->direct ? fleet_direct_parts(h->direct) : 0;
 }
 
+int fleet_step_direct_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
+                          float* terminal_obs) {
+  if (!h || !actions || !obs || !reward || !done || (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
+    if (h) h->error = "fleet_step_direct_dev: null buffer or bad action dtype";
+    return FLEET_ERR_INVALID;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int rc = direct_ready(h, actions, 1, act_dtype, obs, reward, done, terminal_obs, FLEET_LAUNCH_DIRECT_PUBLISH, /*publish=*/true);
+  if (rc != FLEET_OK) return rc;
+  // No release: the state stays in the dies' L2s for the next step; observations, rewards and done flags are stored write-through
+  // by the kernel and are everybody's once the launch has completed (fleet_wait_step).
+  return fleet_direct_submit(h->direct, 1, h->dq_timed, /*release_last=*/false, &h->error);
+}
+
+int fleet_wait_step(fleet_handle h) {
+  if (!h) return FLEET_ERR_INVALID;
+  if (!h->direct) return FLEET_OK;
+  return fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error);
+}
+
+int fleet_direct_placement(fleet_handle h, int32_t map8[8], int32_t* num_xcc, int32_t* any_grid) {
+  if (!h || !map8) return FLEET_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->direct) {
+    const int rc = fleet_direct_open(h->device, &h->direct, &h->error);
+    if (rc != FLEET_OK) return rc;
+  }
+  int m[8], nx = 0, ag = 0;
+  const int rc = fleet_direct_probed(h->direct, m, &nx, &ag);
+  for (int j = 0; j < 8; ++j) map8[j] = m[j];
+  if (num_xcc) *num_xcc = nx;
+  if (any_grid) *any_grid = ag;
+  return rc;
+}
+
+int fleet_direct_split_plan(uint32_t grid_workgroups, int split, uint32_t part_grid[2]) {
+  if (!part_grid) return FLEET_ERR_INVALID;
+  unsigned pg[2];
+  const int parts = fleet_direct_plan(grid_workgroups, split != 0, pg);
+  part_grid[0] = pg[0];
+  part_grid[1] = pg[1];
+  return parts;
+}
+
+int fleet_debug_direct_fault(fleet_handle h, int kind, int tape_row) {
+  if (!h || !h->direct) {
+    if (h) h->error = "fleet_debug_direct_fault: no prepared run (run one through the library's own queue first)";
+    return FLEET_ERR_INVALID;
+  }
+  FLEET_ENTER(h);
+  return fleet_direct_fault(h->direct, kind, tape_row, &h->error);
+}
+
 int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void* tape, int tape_len, int act_dtype, float* obs,
                               double* reward, uint8_t* done, int use_graph) {
   if (!h || regions < 1 || regions > 256) return FLEET_ERR_INVALID;
   FLEET_ENTER(h);
   HIP_TRY(h, hipSetDevice(h->device));
-  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE || use_graph == FLEET_LAUNCH_DIRECT_PUBLISH) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
     h->dq_spans_us.clear();
-    h->dq_timed = true;
+    h->dq_timed = 1;
     int rc = FLEET_OK;
     for (int r = 0; r < regions && rc == FLEET_OK; ++r) rc = fleet_run_tape_dev(h, steps, tape, tape_len, act_dtype, obs, reward, done, use_graph);
-    h->dq_timed = false;
+    h->dq_timed = 0;
     return rc;
   }
   for (auto& e : h->region_events)
@@ -1336,8 +1434,16 @@ int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void*
 int fleet_time_regions_read(fleet_handle h, float* region_ms) {
   FLEET_ENTER(h);
   if (h && region_ms && h->region_events.empty() && !h->dq_spans_us.empty()) {  // (FLEET_ENTER has waited for the runs)
-    for (size_t r = 0; r < h->dq_spans_us.size(); ++r) region_ms[r] = (float)(h->dq_spans_us[r] * 1e-3);
+    bool ok = true;
+    for (size_t r = 0; r < h->dq_spans_us.size(); ++r) {
+      region_ms[r] = (float)(h->dq_spans_us[r] * 1e-3);
+      ok = ok && h->dq_spans_us[r] >= 0.0;  // -1: a packet without dispatch timestamps (a queue whose profiling could not be enabled)
+    }
     h->dq_spans_us.clear();
+    if (!ok) {
+      h->error = "fleet_time_regions_read: a run carries no dispatch timestamps";
+      return FLEET_ERR_HIP;
+    }
     return FLEET_OK;
   }
   if (!h || !region_ms || h->region_events.empty()) return FLEET_ERR_INVALID;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 8
+#define FLEET_ABI_VERSION 9
 
 /* status codes */
 #define FLEET_OK 0
@@ -37,6 +37,9 @@ extern "C" {
 #define FLEET_ERR_HIP 2       /* a HIP runtime call failed                                               */
 #define FLEET_ERR_STATE 3     /* device-side error word set (impossible state, rainflow stack overflow)  */
 #define FLEET_ERR_NODEVICE 4  /* no HIP device: this library has no CPU fallback by design              */
+#define FLEET_ERR_UNSUPPORTED 5 /* the platform does not offer what the requested launch mode relies on (FLEET_LAUNCH_DIRECT:
+                                 no HSA agent at the HIP device's PCI address, a workgroup -> die placement that is not stable);
+                                 use another mode                                                         */
 
 /* FleetParams.deg_mode -- which battery-degradation model runs on the daily 14:45 step                   */
 #define FLEET_DEG_NONE 0      /* calculate_degradation = False                                           */
@@ -64,6 +67,9 @@ extern "C" {
 #define FLEET_DEVERR_DOD_RANGE 8u      /* "DoD too large" :164-167                                                   */
 #define FLEET_DEVERR_TABLE_END 16u     /* episode ran past the last table row                                        */
 #define FLEET_DEVERR_INTERNAL 32u      /* a kernel found its launch arguments inconsistent (a build problem, not a data one) */
+#define FLEET_DEVERR_PLACEMENT 64u     /* a launch of a run on the library's own queue (FLEET_LAUNCH_DIRECT ...) found one of its
+                                          workgroups on another die than the library's probe of that queue says: the run's state
+                                          may be stale, its results are void (a platform problem, not a data one)                */
 
 /*
  * Scalars of one env group (all envs of a handle share tables and parameters).
@@ -346,10 +352,51 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
  * ranges of workgroups on TWO queues, each an in-order chain of its own (the halves drift apart and overlap: 16384 x 50 -17 % per
  * step); FLEET_LAUNCH_DIRECT_ONE_QUEUE never does.  fleet_direct_queues: how the handle's last direct run was laid out (0: none yet). */
 #define FLEET_LAUNCH_DIRECT_ONE_QUEUE 3
+/* FLEET_LAUNCH_DIRECT with the launches of fleet_step_direct_dev (below): every step PUBLISHES its observations, rewards and done flags
+ * (stored write-through, visible to anybody once the launch has completed) while the state stays in the dies' L2s -- the closed-loop
+ * step, fed from a tape: what bench.py times as `closed_loop`. */
+#define FLEET_LAUNCH_DIRECT_PUBLISH 4
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
 
 int fleet_direct_queues(fleet_handle h);
+
+/* ---- closed loop on the library's own queue ---------------------------------------------------------------------------------
+ * fleet_step_dev's contract -- every step's observation is there before the next action is chosen (FleetEnv.step returns it,
+ * /root/reference/fleetrl/fleet_env/fleet_environment.py:436,702) -- on the launch path of FLEET_LAUNCH_DIRECT: ONE launch per call,
+ * written by the library into its own HSA queue, with no release fence.  The env state stays in the dies' L2s from step to step;
+ * what a policy consumes -- obs, reward, done, terminal_obs -- is stored write-through by the kernel and is visible to every later
+ * launch on any stream, to copies and to other processes' reads of the buffers as soon as the launch has completed.
+ *   fleet_step_direct_dev   waits for what the handle's HIP stream was given before (the producer of `actions`: launch it on the
+ *                           handle's stream, or synchronise your own stream first), submits the step, returns at once.  Buffers as
+ *                           fleet_step_dev.  Keep the same buffers from step to step: the launch's argument block is prepared
+ *                           once per set of pointers (another set costs a small upload).  The handle must be on its own stream.
+ *   fleet_wait_step         host wait (spinning, then sleeping) until the submitted steps have completed: their outputs may be read
+ *                           by anybody from then on.  The state is NOT written back by this.
+ * Every other entry point of the handle (fleet_synchronize, fleet_get, fleet_step_dev, fleet_reset_dev ...) first waits for the
+ * steps in flight and has the state written back (one tiny launch that releases at system scope), so the calls mix freely.
+ * Cost per step of the missing write-back and what the write-through stores cost instead: DESIGN.md section 4. */
+int fleet_step_direct_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
+                          float* terminal_obs /* [E,obs_dim] or NULL */);
+int fleet_wait_step(fleet_handle h);
+
+/* What FLEET_LAUNCH_DIRECT / fleet_step_direct_dev rely on, as probed when the handle opened its queue (opens it if need be):
+ * map8[k] = the die (HW_REG_XCC_ID) that chain of probe launches found workgroups w with (w & 7) == k on; num_xcc = dies of the
+ * device; any_grid = 1 if the map also held across launches whose grids are not multiples of 8 workgroups.  The map is information:
+ * the die a queue deals from moves when queues are created in the process, so every chain of launches records the map afresh on the
+ * device and every launch checks the die it runs on against that record (FLEET_DEVERR_PLACEMENT).  FLEET_ERR_UNSUPPORTED: the probe
+ * found the placement not periodic or not stable from launch to launch, and the mode is refused on this platform. */
+int fleet_direct_placement(fleet_handle h, int32_t map8[8], int32_t* num_xcc, int32_t* any_grid);
+/* How a grid of `grid_workgroups` is laid over the handle's queues (a pure function, no device needed): returns 1 (part_grid[0] = the
+ * whole grid) or 2 (two ranges of workgroups: part_grid[0] a multiple of 8 that fits the kernel's 16-bit first-workgroup field). */
+int fleet_direct_split_plan(uint32_t grid_workgroups, int split, uint32_t part_grid[2]);
+/* TEST HOOK for the placement guard (the handle must have run through its own queue before) --
+ * kind 1: the handle's NEXT chain of launches starts from the previous chain's placement record rotated by one workgroup instead of
+ *         recording a fresh one: what its launches would see if the queue's first die had moved in the middle of a chain;
+ * kind 2: in the prepared argument block of tape row `tape_row`, the grid's first workgroup shifted by one (every workgroup steps its
+ *         neighbour's envs: the state IS corrupted).
+ * The next run (through that row) must raise FLEET_DEVERR_PLACEMENT. */
+int fleet_debug_direct_fault(fleet_handle h, int kind, int tape_row);
 
 /* `regions` timed regions of exactly `steps` launches each (as fleet_run_tape_dev), enqueued back to back on the handle's stream
  * with a HIP event before and after each: the kernels' own time per region, without the host's gaps between regions.

@@ -246,3 +246,36 @@ def test_product_build_takes_no_flags_from_the_environment(monkeypatch, tmp_path
     monkeypatch.delenv("FLEET_EXTRA_HIPCC_FLAGS")
     with pytest.raises(ValueError, match="must not overwrite"):
         build.build_variant(build.lib_path(), ["-DFLEET_STAMPS"])
+
+
+def test_direct_split_plan_never_overflows_the_packed_first_workgroup():
+    """A run on the library's own queues may cover the grid with two ranges of workgroups; the second range's first workgroup travels in
+    16 bits of a kernel argument (fleet_kernels.hip `p_N`).  ADVICE r5: nothing bounded it -- grids above ~131 000 workgroups would have
+    wrapped the field, stepped the first half twice and the second half never.  The plan is a pure function of the grid."""
+    lib = _capi.load_library()
+    pg = (ctypes.c_uint32 * 2)()
+
+    def plan(grid, split=1):
+        parts = lib.fleet_direct_split_plan(grid, split, pg)
+        return parts, pg[0], pg[1]
+
+    assert plan(4096, 0) == (1, 4096, 0)                 # not asked to split
+    assert plan(15) == (1, 15, 0)                        # too small to split
+    assert plan(16) == (2, 8, 8)
+    assert plan(4096) == (2, 2048, 2048)
+    assert plan(1027) == (2, 520, 507)                   # the first range is a multiple of 8: env e keeps its die in the second
+    for grid in (131040, 131056, 131057):                # the largest grids whose first range (65 528 workgroups) still fits 16 bits
+        parts, a, b = plan(grid)
+        assert parts == 2 and a % 8 == 0 and a <= 0xFFFF and a + b == grid
+    for grid in (131058, 131072, 131080, 262144, 1 << 20, (1 << 31) - 1):  # beyond: ONE range, never a wrapped field
+        assert plan(grid) == (1, grid, 0)
+
+
+def test_library_and_code_object_carry_the_same_source_hash():
+    """fleet_direct_open refuses a code object that was not compiled from the library's sources (both carry `FLEET_SRC_SHA`)."""
+    from fleetrl_amd import build
+
+    build.build()
+    sha = build.source_sha().encode()
+    assert sha in open(build.lib_path(), "rb").read()
+    assert sha in open(build.code_object_path(), "rb").read()

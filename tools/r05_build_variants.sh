@@ -5,7 +5,8 @@ cd "$(dirname "$0")/.." && mkdir -p ab_variants && rm -f ab_variants/*.so ab_var
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12"
 for spec in "$@"; do
   tag="${spec%%=*}"; rest="${spec#*=}"; src="${rest%%|*}"; flags="${rest#*|}"; [ "$flags" = "$rest" ] && flags=""
-  if [ "$src" = "." ]; then dir=.; else dir=$(mktemp -d /tmp/r05src.XXXX); git archive "$src" fleetrl_amd/csrc include | tar -x -C "$dir"; fi
+  if [ "$src" = "." ]; then dir=.; else dir=$(mktemp -d /tmp/r05src.XXXX); git archive "$src" fleetrl_amd/csrc include | tar -x -C "$dir"; sed -i "s/#define FLEET_ABI_VERSION .*/$(grep '#define FLEET_ABI_VERSION' include/fleet_hip.h)/" "$dir/include/fleet_hip.h"; fi  # (an older revision answers to the tree's ABI number: the public structures have not changed since version 4)
+  sha="-DFLEET_SRC_SHA=\"v_$(cat $dir/fleetrl_amd/csrc/* | sha256sum | cut -c1-12)_$(echo "$flags" | sha256sum | cut -c1-8)\""; flags="$flags $sha"
   if [ -f "$dir/fleetrl_amd/csrc/fleet_direct.hip" ]; then  # sources with the library's own launch queue: the kernels' code object beside the library
     ( /opt/rocm/bin/hipcc $FLAGS -shared $flags "$dir/fleetrl_amd/csrc/fleet_kernels.hip" "$dir/fleetrl_amd/csrc/fleet_capi.hip" "$dir/fleetrl_amd/csrc/fleet_direct.hip" -L/opt/rocm/lib -lhsa-runtime64 -o ab_variants/$tag.so || echo "BUILD FAILED: $tag" ) &
     ( /opt/rocm/bin/hipcc --genco --no-gpu-bundle-output ${FLAGS/-fPIC/} $flags "$dir/fleetrl_amd/csrc/fleet_kernels.hip" -o ab_variants/$tag.gfx950.hsaco || echo "BUILD FAILED: $tag (code object)" ) &

@@ -20,7 +20,7 @@ from fleetrl_amd.params import make_params, time_features  # noqa: E402
 from fleetrl_amd.synth import synth_tables  # noqa: E402
 
 E, N = int(os.environ.get("E", 4096)), 50
-rc = resolve_config(bench_config(E, N, "ct"))
+rc = resolve_config(bench_config(E, N, "ct", deg=os.environ.get("DEG", "rainflow")))  # DEG=none|linear: diagnostics
 tb = synth_tables("ct", N)
 b = FleetBatch(make_params(rc, tb, E, seed=0), tb, time_features(tb))
 dev = torch.device("cuda", 0)
