@@ -96,9 +96,9 @@ def kernel_source_sha() -> str:
 
 def committed_traffic(config: str, envs: int, evs: int, launch_mode: str = "direct"):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command (tools/prof_traffic.sh ->
-    profiles/r05_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
+    profiles/r06_traffic_<config>.json); (None, why) when the profile is absent, was taken on another kernel source or shape.
     The counters need rocprofv3, so they cannot be read inside this run: the figure is looked up, and `traffic_source` says so."""
-    for name in (f"r05_traffic_{config}.json", f"r05_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
+    for name in (f"r06_traffic_{config}.json", f"r06_traffic_{envs}x{evs}.json"):  # the config's own shape, or an override's
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -222,19 +222,28 @@ def main():
     ap.add_argument("--evs", type=int, default=None, help="override the config's EVs per env")
     ap.add_argument("--use-case", default=None, help="override the config's fleet type(s) with one type")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--launch", choices=("graph", "eager", "direct", "direct1", "publish"), default="direct",
-                    help="how the K launches of a region reach the GPU: a replayed hipGraph (eager below 64 steps), one hipLaunchKernel "
-                         "each, or AQL packets written by the library into a queue of its own without the L2 write-back HIP attaches "
-                         "to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT; a batch of >= 6144 wavefronts goes to two queues, "
-                         "direct1 keeps it on one)")
+    ap.add_argument("--launch", choices=("graph", "eager", "direct", "direct1"), default="direct",
+                    help="how the K launches of a region reach the GPU.  direct (default): AQL packets written by the library into a queue "
+                         "of its own without the L2 write-back HIP attaches to every kernel boundary (fleet_hip.h FLEET_LAUNCH_DIRECT; a "
+                         "batch of >= 6144 wavefronts goes to two queues, direct1 keeps it on one) -- an OPEN-LOOP replay: a step's outputs "
+                         "are visible after the region only; graph: a replayed hipGraph (eager below 64 steps), eager: one hipLaunchKernel "
+                         "each -- CLOSED LOOP: every step's outputs are visible before the next step starts, what fleet_step_dev and every "
+                         "Gym / SB3 loop get.  The kernel time of the other path is reported beside the headline's "
+                         "(roofline.other_launch_paths)")
+    ap.add_argument("--phase", choices=("locked", "staggered"), default="locked",
+                    help="locked (default): all envs start their episodes together and stay in lock step -- what the reference's vec env "
+                         "does by construction (fixed-length episodes, every env auto-resets on the same step); a launch's duration then "
+                         "depends on the episode step it is and one launch in 192 resets every env.  staggered: the envs' episodes are "
+                         "de-phased first (masked resets spread over one episode length), so that every launch sees the stationary mixture "
+                         "of episode ages and ends a few episodes.  Whichever is timed, the other's kernel time is reported beside it "
+                         "(roofline.other_phase)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--tape-len", type=int, default=None,
-                    help="steps of the device-resident action tape (replayed cyclically); default: as many as fit --tape-mb, 2 ... 64")
-    ap.add_argument("--tape-mb", type=float, default=32.0,
-                    help="size budget of the action tape: it stands in for a policy's output buffer, which a real loop rewrites every "
-                         "step -- a tape far larger than that (64 steps of the c5 shard are 420 MB, more than the 256 MB Infinity "
-                         "Cache) would make the run measure the streaming of its own input")
+    ap.add_argument("--tape-len", type=int, default=32,
+                    help="independent rows of the device-resident action tape (replayed cyclically; a run of fewer steps uses as many rows "
+                         "as it has steps).  32 at every shape: a much shorter tape is another workload -- the same few action vectors "
+                         "repeated forever drive every battery to its limit and the rainflow push drops out of the step "
+                         "(config.workload_invariants says what the run did)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (with --device-index) only exists to smoke-test the multi-rank control "
                          "flow with several ranks on ONE GPU, which RCCL refuses")
@@ -289,15 +298,14 @@ def main():
     E = args.envs_per_gpu or spec["envs"]
     N = args.evs or spec["evs"]
     # action tape: L steps of [E, N] float32 actions, replayed cyclically
-    tape_len = args.tape_len if args.tape_len else max(2, min(64, int(args.tape_mb * 2**20 // (E * N * 4))))
-    L = max(1, min(tape_len, args.steps))
+    L = max(1, min(args.tape_len, args.steps))
     graph_len = L * ((64 + L - 1) // L)  # launches per captured graph: whole tape cycles, at least 64 (fleet_run_tape_dev)
     # launches go through a captured hipGraph of L steps; a run shorter than 64 steps launches eagerly (one graph launch costs
     # about as much as six kernel launches on the host: 9.9 vs 9.65 us per step measured for the driver's 20-step regions)
     launch_mode = "eager" if args.no_graph else args.launch
     if launch_mode == "graph" and args.steps < 64:
         launch_mode = "eager"
-    use_graph = {"eager": 0, "graph": 1, "direct": 2, "direct1": 3, "publish": 4}[launch_mode]  # _capi.LAUNCH_*
+    use_graph = {"eager": 0, "graph": 1, "direct": 2, "direct1": 3}[launch_mode]  # _capi.LAUNCH_*
     launch_note = ""
     groups, off = [], 0
     for k, uc in enumerate(spec["groups"]):
@@ -329,30 +337,73 @@ def main():
             use_graph = {"eager": 0, "graph": 1}[launch_mode]
         for g in groups:
             g.batch.reset_dev(g.obs.data_ptr())
-    # clock ramp: replay the same step (untimed) for a fixed wall time before the W warmup steps, so that a short
-    # --steps/--warmup run measures the same steady state as a long one
-    t_prime = time.perf_counter()
-    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
-        run(4 * L)
-        sync()
-    run(args.warmup)
-    sync()
-    ret = torch.zeros(E, device=dev, dtype=torch.float64)
-    ln = torch.zeros(E, device=dev, dtype=torch.int32)
-    gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
-
     def barrier():
         torch.cuda.synchronize()
         if launched:  # one rank: the synchronize IS the barrier (a second one would only add host time to every timed region)
             dist.barrier()
             torch.cuda.synchronize()
 
+    reps = args.reps if args.reps else (31 if args.steps <= 256 else 7)
+    n_ev = max(3, min(reps, 15))
+
+    def kernel_regions(mode):
+        """The kernels' own time for `n_ev` regions of exactly K launches through launch path `mode`, [region][group] in ms: HIP events
+        on the streams the kernels run on -- or, for the library's own queue, which no HIP event can bracket, the dispatch timestamps
+        of each region's first and last packet (start of the first launch to end of the last).  The regions are enqueued back to
+        back and read afterwards: no host gap between them, so a short region measures the same running kernel as a long one."""
+        barrier()
+        for g in groups:
+            g.batch.time_regions_begin(n_ev, args.steps, g.tape.data_ptr(), g.L, g.obs.data_ptr(), g.reward.data_ptr(), g.done.data_ptr(),
+                                       use_graph=mode)
+        per_group = [g.batch.time_regions_read() for g in groups]
+        return [[float(pg[i]) for pg in per_group] for i in range(n_ev)]
+
+    def kernel_ms(mode):
+        regs = kernel_regions(mode)
+        return max(sorted(regs, key=max)[len(regs) // 2]) / args.steps
+
+    # clock ramp: replay the same step (untimed) for a fixed wall time before the W warmup steps, so that a short
+    # --steps/--warmup run measures the same steady state as a long one
+    t_prime = time.perf_counter()
+    while (time.perf_counter() - t_prime) * 1e3 < args.prime_ms:
+        run(4 * L)
+        sync()
+    # ---- episode phase -------------------------------------------------------------------------------------------------------
+    # After a plain reset all envs run their 192-step episodes in lock step -- the reference's vec env does by construction (every env
+    # has the same episode_length and is auto-reset on the step it ends: complete_pipeline.ipynb cell 13, fleet_environment.py:627-628).
+    # A launch's duration then depends on WHICH episode step it is (nothing is pushed at step 0, closures carry stress towards the
+    # end) and one launch in 192 resets every env.  Staggered: env e is reset once more after (e * 2654435761 mod 2^32) mod S further
+    # steps, so the episode ages are uniform over 0 .. S-1 and every launch is the stationary mixture (1/S of the envs end their
+    # episode in it -- and the few wavefronts that reset their env then set every launch's duration).
+    S_ep = groups[0].rc.episode_length * (60 // groups[0].rc.minutes)
+
+    def stagger():
+        for g in groups:
+            g.batch.reset_dev(g.obs.data_ptr())
+            ph = (torch.arange(g.E, device=dev, dtype=torch.int64) * 2654435761 % (1 << 32)) % S_ep
+            g.masks = (ph[None, :] == torch.arange(S_ep, device=dev)[:, None]).to(torch.uint8).contiguous()
+        torch.cuda.synchronize()
+        for k in range(1, S_ep):  # (phase 0 keeps the reset it has just had)
+            for g in groups:
+                g.batch.step_dev(g.tape[k % g.L].data_ptr(), g.obs.data_ptr(), g.reward.data_ptr(), g.done.data_ptr())
+                g.batch.reset_dev(g.obs.data_ptr(), g.masks[k].data_ptr())
+        sync()
+        for g in groups:
+            del g.masks
+
+    if args.phase == "staggered":
+        stagger()
+    run(args.warmup)
+    sync()
+    ret = torch.zeros(E, device=dev, dtype=torch.float64)
+    ln = torch.zeros(E, device=dev, dtype=torch.int32)
+    gather_episode_stats(ret.to(cdev), ln.to(cdev), equal_shards=True)  # warmup of the logging collective too (RCCL channel setup is not a per-step cost)
+
     # ---- the timed regions: each is exactly K steps between two barriers ------------------------------------------------------
     # One region is what the contract describes (barrier + synchronize, K launches, synchronize + barrier).  A single region of
     # a short run mostly measures the host's wake-up after the synchronize (tens of microseconds against 20 launches of 9 us), so
     # R regions are run back to back and the MEDIAN one is reported (`reps`, with the fastest and slowest beside it); inside a
     # region the wait for the device is a spin on hipStreamQuery instead of a blocking synchronize.
-    reps = args.reps if args.reps else (31 if args.steps <= 256 else 7)
     walls = []
     for _ in range(reps):
         barrier()
@@ -362,17 +413,49 @@ def main():
             g.batch.spin_wait()
         barrier()
         walls.append(time.perf_counter() - t0)
-    # the kernels' own time (roofline): HIP events on the streams the kernels run on, around regions of the same K launches
-    # (kept out of the wall-clock regions: two more operations on each stream per region).  The regions are enqueued back to
-    # back, each between its own pair of events, and read afterwards: no host gap between them, so a short region measures the
-    # same running kernel as a long one (a 20-launch region behind a host synchronize starts on a chip that has idled)
-    n_ev = max(3, min(reps, 15))
-    barrier()
-    for g in groups:
-        g.batch.time_regions_begin(n_ev, args.steps, g.tape.data_ptr(), g.L, g.obs.data_ptr(), g.reward.data_ptr(), g.done.data_ptr(),
-                                   use_graph=use_graph)
-    per_group = [g.batch.time_regions_read() for g in groups]
-    ev_regions = [[float(pg[i]) for pg in per_group] for i in range(n_ev)]
+    # the kernels' own time (roofline), kept out of the wall-clock regions (kernel_regions above) -- through the headline's launch
+    # path, then through the other paths of the same kernel on the same state (reported beside it, never as `value`)
+    ev_regions = kernel_regions(use_graph)
+    other_paths = {}
+    for name, mode, what in (
+            ("open_loop_direct_queue", 2, "OPEN LOOP: the library's own queue, no L2 write-back between the launches of a region; a step's "
+                                          "outputs are visible after the region only (FLEET_LAUNCH_DIRECT: a recorded tape, an open-loop rollout)"),
+            ("closed_loop_hip_graph" if args.steps >= graph_len else "closed_loop_hip_eager", 1 if args.steps >= graph_len else 0,
+             "CLOSED LOOP: HIP's launches, an agent-scope release (L2 write-back) at every kernel boundary -- every step's outputs are "
+             "visible before the next step starts: what fleet_step_dev and every Gym / SB3 loop get")):
+        if (mode >= 2) != (use_graph >= 2):
+            try:
+                other_paths[name] = {"kernel_ms": kernel_ms(mode), "what": what}
+            except Exception as ex:  # (no queue to be had: see launch_note)
+                other_paths[name] = {"kernel_ms": None, "what": f"unavailable: {ex}"}
+    # ---- what the run did: the workload's invariants over a window of W launches (envs that end an episode inside it left out) --
+    W_inv = 16
+    try:
+        inv_before = [(g.batch.get("episodes"), g.batch.get("rf_cycles"), g.batch.get("rf_stack")) for g in groups]
+        run(W_inv)
+        sync()
+        pushes = closures = evsteps = 0
+        for g, (e0, c0, s0) in zip(groups, inv_before):
+            keep = g.batch.get("episodes") == e0
+            dc = (g.batch.get("rf_cycles").astype(np.int64) - c0)[keep].sum()
+            ds = (g.batch.get("rf_stack").astype(np.int64) - s0)[keep].sum()
+            closures += int(dc)
+            pushes += int(ds + 2 * dc)  # a push adds a point, a full cycle removes two (a half cycle one: an upper bound, exact without them)
+            evsteps += int(keep.sum()) * g.N * W_inv
+        invariants = {"push_fraction": pushes / max(evsteps, 1), "closure_fraction": closures / max(evsteps, 1), "window_steps": W_inv,
+                      "ev_steps": evsteps, "what": "share of the EV-steps that push a rainflow reversal point / close a rainflow cycle"}
+    except Exception as ex:  # (an older library run beside the tree by the A/B scripts: no such fields)
+        invariants = {"push_fraction": None, "closure_fraction": None, "what": f"unavailable: {ex}"}
+    # ---- the same launches in the OTHER episode phase (kernel time only) ------------------------------------------------------------
+    if args.phase == "locked":
+        stagger()
+        run(args.warmup)
+    else:
+        for g in groups:
+            g.batch.reset_dev(g.obs.data_ptr())
+        run(args.warmup + 7)
+    sync()
+    other_phase_ms = kernel_ms(use_graph)
     w = torch.tensor(walls, device=cdev, dtype=torch.float64)
     if launched:
         dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
@@ -483,11 +566,25 @@ def main():
                                    else (None, "diagnostic override of the workload"))
         graph_used = use_graph == 1 and args.steps >= graph_len
         n_queues = max(g.batch.direct_queues() for g in groups) if use_graph >= 2 else 0
-        launch_desc = launch_note + ((f"hipGraph of {graph_len} launches" if graph_used else "eager") if use_graph < 2 else
-                                     "AQL packets written by the library into " + ("an HSA queue" if n_queues < 2 else "two HSA queues") +
-                                     " of its own (FLEET_LAUNCH_DIRECT): every launch invalidates the per-CU caches, only the last launch "
-                                     "of a region writes the L2s back" +
-                                     ("; the batch as two ranges of workgroups, one in-order chain per queue" if n_queues == 2 else ""))
+        if use_graph < 2:
+            launch_desc = launch_note + (f"hipGraph of {graph_len} launches" if graph_used else "eager") + \
+                          ": HIP's launches, an agent-scope release (L2 write-back) at every kernel boundary; CLOSED LOOP: every step's " \
+                          "outputs are visible before the next step starts"
+        else:
+            launch_desc = ("AQL packets written by the library into " + ("an HSA queue" if n_queues < 2 else "two HSA queues") + " of its own "
+                           "(FLEET_LAUNCH_DIRECT): every launch invalidates the per-CU caches, only the last launch of a region writes the "
+                           "dies' L2s back (the env state stays there from step to step; every region records the queue's workgroup -> die "
+                           "placement and every launch checks the die it runs on against it); OPEN LOOP: a step's outputs are visible after "
+                           "the region only (tape replay)" +
+                           ("; the batch as two ranges of workgroups, one in-order chain per queue" if n_queues == 2 else ""))
+
+        def path_line(kms):
+            a = bytes_launch / (kms * 1e-3) / 1e9
+            return {"kernel_ms": kms, "achieved": a, "frac": a / HBM_PEAK_GBS}
+
+        paths = {}
+        for name, v in other_paths.items():
+            paths[name] = dict(path_line(v["kernel_ms"]), what=v["what"]) if v["kernel_ms"] else v
         out = {
             "metric": "env-steps/sec (num_envs x EVs batch, 1 launch per step)",
             "value": world * E * args.steps / wall,
@@ -510,7 +607,13 @@ def main():
                        "name": args.config, "envs_per_gpu": E, "evs_per_env": N, "obs_dim": g0.batch.obs_dim,
                        "groups": [{"use_case": g.use_case, "envs": g.E} for g in groups],
                        "launch": launch_desc, "launch_mode": launch_mode, "launches_per_step": len(groups) * max(1, n_queues), "prime_ms": args.prime_ms,
-                       "action_tape": f"{L} steps x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
+                       "closed_loop": use_graph < 2,  # every step's outputs are visible before the next step starts
+                       "action_tape": f"{L} independent rows x {E * N * 4 / 2**20:.2f} MB of float32 actions resident in HBM, replayed cyclically",
+                       "episode_phase": (f"staggered: episode ages uniform over the {S_ep} steps of an episode, every launch ends "
+                                         f"~1/{S_ep} of the episodes (--phase staggered)" if args.phase == "staggered" else
+                                         f"locked: all envs in the same episode step, one launch in {S_ep} resets every env -- the "
+                                         "reference's vec env by construction (--phase locked)"),
+                       "workload_invariants": invariants,
                        "ev_steps_per_s": world * E * N * args.steps / wall},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -518,7 +621,14 @@ def main():
                          "kernel_ms_ranks_min": min(k_ranks), "kernel_ms_ranks_max": max(k_ranks),
                          "kernel_src_sha": kernel_source_sha(),
                          "algorithmic_bytes_per_env_step": bytes_launch / E, "bytes_per_launch": bytes_launch,
-                         "kernel_ms_event_pair_per_launch": float(np.mean(per))},
+                         "kernel_ms_event_pair_per_launch": float(np.mean(per)),
+                         "launch_mode": launch_mode,
+                         "note": "frac = algorithmic bytes per launch / average launch duration / 8 TB/s: the state, the observation rows "
+                                 "and the action tape of this shape sit in the 256 MiB Infinity Cache, so this is a rate of algorithmic "
+                                 "bytes against the HBM peak, not measured HBM traffic (`traffic`: rocprofv3 counters)",
+                         # the same kernel on the same state through the other launch paths (kernel time only; never `value`)
+                         "other_launch_paths": paths,
+                         "other_phase": dict(path_line(other_phase_ms), phase="staggered" if args.phase == "locked" else "locked")},
             # K steps per launch: only the last step's observation is part of the result (and written), so the
             # algorithmic bytes per env-step are smaller by the observation row for K-1 of the K steps
             "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * many_reps / (many_ms * 1e-3),

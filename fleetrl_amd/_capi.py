@@ -18,7 +18,7 @@ DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
 PICK_STATIC, PICK_RANDOM, PICK_EVAL = 0, 1, 2
 ACT_F32, ACT_F64 = 0, 1
 # fleet_run_tape_dev / fleet_time_regions_begin: how the launches reach the GPU (include/fleet_hip.h FLEET_LAUNCH_*)
-LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT, LAUNCH_DIRECT_ONE_QUEUE, LAUNCH_DIRECT_PUBLISH = 0, 1, 2, 3, 4
+LAUNCH_EAGER, LAUNCH_GRAPH, LAUNCH_DIRECT, LAUNCH_DIRECT_ONE_QUEUE = 0, 1, 2, 3
 POLICY_UNCONTROLLED, POLICY_DISTRIBUTED, POLICY_NIGHT = 2, 3, 4
 
 DEVERR_OBS_FORMAT, DEVERR_NEG_LIFE, DEVERR_SOH_MISMATCH, DEVERR_DOD_RANGE, DEVERR_TABLE_END, DEVERR_INTERNAL, DEVERR_PLACEMENT = 1, 2, 4, 8, 16, 32, 64
@@ -46,6 +46,8 @@ FIELDS = {
     "episodes": (18, np.int32, False),
     "penalty_record": (19, np.float64, False),
     "last_ep_len_f64": (20, np.float64, False),
+    "rf_cycles": (21, np.int32, True),
+    "rf_stack": (22, np.int32, True),
 }
 
 _I32_FIELDS = (
@@ -218,13 +220,11 @@ def load_library():
     if hasattr(lib, "fleet_direct_queues"):  # (absent from older libraries the A/B scripts run beside the tree's)
         lib.fleet_direct_queues.argtypes = [vp]
         lib.fleet_direct_queues.restype = C.c_int
-    if hasattr(lib, "fleet_step_direct_dev"):  # (ABI 9; absent from older libraries the A/B scripts run beside the tree's)
-        lib.fleet_step_direct_dev.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
-        lib.fleet_wait_step.argtypes = [vp]
+    if hasattr(lib, "fleet_direct_placement"):  # (ABI 9; absent from older libraries the A/B scripts run beside the tree's)
         lib.fleet_direct_placement.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.fleet_direct_split_plan.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         lib.fleet_debug_direct_fault.argtypes = [vp, C.c_int, C.c_int]
-        for name in ("fleet_step_direct_dev", "fleet_wait_step", "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault"):
+        for name in ("fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault"):
             getattr(lib, name).restype = C.c_int
     if hasattr(lib, "fleet_selftest_stress"):
         lib.fleet_selftest_stress.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
@@ -256,5 +256,5 @@ EXPORTED_SYMBOLS = (
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
     "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues", "fleet_selftest_stress",
-    "fleet_step_direct_dev", "fleet_wait_step", "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault",
+    "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault",
 )

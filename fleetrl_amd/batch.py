@@ -303,17 +303,6 @@ class FleetBatch:
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,
                                                  reward_ptr, done_ptr, int(use_graph)))
 
-    def step_direct_dev(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, terminal_ptr: int | None = None,
-                        act_dtype: int = _capi.ACT_F32):
-        """One step through the library's own queue, closed loop (fleet_step_direct_dev): no release fence -- the state stays in the
-        dies' L2s --, observations / rewards / done flags stored write-through.  Asynchronous; `wait_step()` before anybody reads
-        the outputs.  Every other call on the batch writes the state back first, so the calls mix freely."""
-        self._check(self.lib.fleet_step_direct_dev(self.h, actions_ptr, act_dtype, obs_ptr, reward_ptr, done_ptr, terminal_ptr))
-
-    def wait_step(self):
-        """Host wait for the steps submitted with `step_direct_dev`: their outputs are visible to every stream and to copies."""
-        self._check(self.lib.fleet_wait_step(self.h))
-
     def direct_placement(self):
         """(map8, num_xcc, any_grid): the workgroup -> die map the batch's own queue was probed to have (fleet_direct_placement)."""
         m = (C.c_int32 * 8)()

@@ -133,7 +133,6 @@ struct Batch {
   float* dq_term = nullptr;
   double* dq_reward = nullptr;
   uint8_t* dq_done = nullptr;
-  bool dq_publish = false;  // the prepared launch is the instance that stores its outputs write-through (closed-loop steps)
   uint64_t dq_gen = 0;   // the handle's generation the prepared argument blocks were made in
   int dq_timed = 0;      // 0 / 1 (first and last packet of a run) / 2 (every packet): fleet_direct_submit
   std::vector<double> dq_spans_us;
@@ -143,11 +142,9 @@ struct Batch {
 };
 
 // A run submitted to the handle's own queue is not on its HIP stream: every entry point that touches the handle waits for it first.
-// ... and, if its launches left state in the dies' L2s (no release fence between steps), has that written back: whatever the entry
-// point then launches on the HIP stream -- on any die -- or copies to the host reads what the run wrote.
 static int direct_drain(Batch* h) {
   if (!h || !h->direct) return FLEET_OK;
-  return fleet_direct_release(h->direct, &h->dq_spans_us, &h->error);
+  return fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error);
 }
 #define FLEET_ENTER(h)                          \
   do {                                          \
@@ -1022,7 +1019,7 @@ static size_t field_bytes(const FleetDev& d, int field) {
   switch (field) {
     case FLEET_F_SOC: case FLEET_F_SOH: case FLEET_F_SOC_DEG: case FLEET_F_TARGET_SOC: case FLEET_F_FD_CYC:
     case FLEET_F_FD_CAL: case FLEET_F_SEI_L: bytes = EN * 8; break;
-    case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: bytes = EN * 4; break;
+    case FLEET_F_HOURS_LEFT: case FLEET_F_RF_LEN: case FLEET_F_RF_CYCLES: case FLEET_F_RF_STACK: bytes = EN * 4; break;
     case FLEET_F_CASHFLOW: case FLEET_F_EP_RETURN: case FLEET_F_LAST_EP_RETURN: case FLEET_F_PENALTY_RECORD:
     case FLEET_F_LAST_EP_LEN_F64:
     bytes = E * 8; break;
@@ -1233,7 +1230,7 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms) {
 // hash, placement probe), the launch's argument blocks describe exactly these buffers on the handle as it is now, and everything the
 // HIP stream was given before has completed.  `tape`: tape_len rows of actions (a closed-loop step: one row).
 static int direct_ready(fleet_handle h, const void* tape, int tape_len, int act_dtype, float* obs, double* reward, uint8_t* done,
-                        float* terminal_obs, int mode, bool publish) {
+                        float* terminal_obs, int mode) {
   if (h->stream != h->own_stream) {
     // a run is not ordered on a HIP stream: ops queued on a borrowed stream (torch's) after the call would read its outputs too early
     // and nothing could tell them.  The handle's own stream is never handed to anybody else's ops.
@@ -1242,7 +1239,7 @@ static int direct_ready(fleet_handle h, const void* tape, int tape_len, int act_
     return FLEET_ERR_INVALID;
   }
   const bool stale = !h->direct || h->dq_gen != h->gen || h->dq_tape != tape || h->dq_len != tape_len || h->dq_dtype != act_dtype ||
-                     h->dq_obs != obs || h->dq_term != terminal_obs || h->dq_reward != reward || h->dq_done != done || h->dq_mode != mode || h->dq_publish != publish;
+                     h->dq_obs != obs || h->dq_term != terminal_obs || h->dq_reward != reward || h->dq_done != done || h->dq_mode != mode;
   if (stale) {
     // (the launches in flight read the argument blocks that are about to be replaced)
     int rc = h->direct ? fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error) : FLEET_OK;
@@ -1252,7 +1249,7 @@ static int direct_ready(fleet_handle h, const void* tape, int tape_len, int act_
       if (rc != FLEET_OK) return rc;
     }
     FleetStepLaunch L;
-    const hipError_t e = fleet_describe_step(h->d, tape, act_dtype, obs, reward, done, terminal_obs, publish, &L);
+    const hipError_t e = fleet_describe_step(h->d, tape, act_dtype, obs, reward, done, terminal_obs, &L);
     if (e != hipSuccess) {
       h->error = "direct submission serves single-step launches only (no real_time, no data log)";
       return FLEET_ERR_INVALID;
@@ -1262,21 +1259,13 @@ static int direct_ready(fleet_handle h, const void* tape, int tape_len, int act_
 #ifndef FLEET_DIRECT_SPLIT_WAVES
 #define FLEET_DIRECT_SPLIT_WAVES 6144
 #endif
-    const bool split = (mode == FLEET_LAUNCH_DIRECT || mode == FLEET_LAUNCH_DIRECT_PUBLISH) && h->d.N <= 64 && (size_t)L.grid * (L.block / 64) >= FLEET_DIRECT_SPLIT_WAVES;
-    // Two layouts of the same batch put the second half of the envs on different queues, and every queue deals its workgroups to the
-    // dies from a die of its own (tools/ubench/xcc_map.cpp): state that the previous layout's launches left in the L2s is written back
-    // before the layout may change
-    if (fleet_direct_dirty(h->direct)) {
-      unsigned pg[2];
-      if (fleet_direct_plan(L.grid, split, pg) != fleet_direct_parts(h->direct) && (rc = fleet_direct_release(h->direct, &h->dq_spans_us, &h->error)) != FLEET_OK)
-        return rc;
-    }
+    const bool split = mode == FLEET_LAUNCH_DIRECT && h->d.N <= 64 && (size_t)L.grid * (L.block / 64) >= FLEET_DIRECT_SPLIT_WAVES;
     h->dq_tape = nullptr;  // whatever happens below, the old key describes nothing any more
     h->dq_len = 0;
     const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
     rc = fleet_direct_prepare(h->direct, L, tape, tape_len, row, split, &h->error);
     if (rc != FLEET_OK) return rc;
-    h->dq_mode = mode; h->dq_gen = h->gen; h->dq_publish = publish;
+    h->dq_mode = mode; h->dq_gen = h->gen;
     h->dq_tape = tape; h->dq_len = tape_len; h->dq_dtype = act_dtype; h->dq_obs = obs; h->dq_term = terminal_obs; h->dq_reward = reward; h->dq_done = done;
   }
   // what the stream was given before (a reset, a copy of actions ...) has completed before the first packet is written
@@ -1294,14 +1283,13 @@ int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t row = (size_t)h->d.E * h->d.N * (act_dtype == FLEET_ACT_F64 ? 8 : 4);
   const char* base = static_cast<const char*>(tape);
-  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE || use_graph == FLEET_LAUNCH_DIRECT_PUBLISH) {
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {
     // the library's own AQL packets: the launches of the run keep their state in the dies' L2s (fleet_direct.hip), the last one
     // writes it back.  Asynchronous like the other forms; not on the HIP stream -- the next call on the handle waits for the run.
-    // _PUBLISH: the launches of fleet_step_direct_dev (outputs stored write-through), fed from the tape.
     if (steps == 0) return FLEET_OK;
-    const int rc = direct_ready(h, tape, tape_len, act_dtype, obs, reward, done, nullptr, use_graph, use_graph == FLEET_LAUNCH_DIRECT_PUBLISH);
+    const int rc = direct_ready(h, tape, tape_len, act_dtype, obs, reward, done, nullptr, use_graph);
     if (rc != FLEET_OK) return rc;
-    return fleet_direct_submit(h->direct, steps, h->dq_timed, /*release_last=*/true, &h->error);
+    return fleet_direct_submit(h->direct, steps, h->dq_timed, &h->error);
   }
   FLEET_ENTER(h);
   int i = 0;
@@ -1352,26 +1340,6 @@ int fleet_direct_queues(fleet_handle h) {
   return h->direct ? fleet_direct_parts(h->direct) : 0;
 }
 
-int fleet_step_direct_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
-                          float* terminal_obs) {
-  if (!h || !actions || !obs || !reward || !done || (act_dtype != FLEET_ACT_F32 && act_dtype != FLEET_ACT_F64)) {
-    if (h) h->error = "fleet_step_direct_dev: null buffer or bad action dtype";
-    return FLEET_ERR_INVALID;
-  }
-  HIP_TRY(h, hipSetDevice(h->device));
-  const int rc = direct_ready(h, actions, 1, act_dtype, obs, reward, done, terminal_obs, FLEET_LAUNCH_DIRECT_PUBLISH, /*publish=*/true);
-  if (rc != FLEET_OK) return rc;
-  // No release: the state stays in the dies' L2s for the next step; observations, rewards and done flags are stored write-through
-  // by the kernel and are everybody's once the launch has completed (fleet_wait_step).
-  return fleet_direct_submit(h->direct, 1, h->dq_timed, /*release_last=*/false, &h->error);
-}
-
-int fleet_wait_step(fleet_handle h) {
-  if (!h) return FLEET_ERR_INVALID;
-  if (!h->direct) return FLEET_OK;
-  return fleet_direct_wait(h->direct, &h->dq_spans_us, &h->error);
-}
-
 int fleet_direct_placement(fleet_handle h, int32_t map8[8], int32_t* num_xcc, int32_t* any_grid) {
   if (!h || !map8) return FLEET_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1410,7 +1378,7 @@ int fleet_time_regions_begin(fleet_handle h, int regions, int steps, const void*
   if (!h || regions < 1 || regions > 256) return FLEET_ERR_INVALID;
   FLEET_ENTER(h);
   HIP_TRY(h, hipSetDevice(h->device));
-  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE || use_graph == FLEET_LAUNCH_DIRECT_PUBLISH) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
+  if (use_graph == FLEET_LAUNCH_DIRECT || use_graph == FLEET_LAUNCH_DIRECT_ONE_QUEUE) {  // the runs' own dispatch timestamps: start of the first launch -> end of the last
     h->dq_spans_us.clear();
     h->dq_timed = 1;
     int rc = FLEET_OK;

@@ -251,16 +251,15 @@ hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dty
 // copies of the action pointer sit in it (a tape replay patches them per step).  host_fn == nullptr / hipErrorNotSupported: not a
 // single-step configuration (real_time, data log).
 struct FleetStepLaunch {
-  bool publish;  // in: describe the instance that stores its outputs write-through (a step whose packet carries no release fence)
   const void* host_fn;
   unsigned grid, block, args_bytes;
   unsigned actions_offset[2];
   unsigned packed_n_offset;  // where `p_N` sits: EVs per env | first workgroup of the grid << 16 (a run split over two queues)
-  unsigned guard_offset;     // where the pointer to the placement guard's record sits (nullptr = no check: every launch through HIP)
+  unsigned guard_offset;     // where the eight bytes of the placement record sit (zeros = no check: every launch through HIP)
   alignas(8) unsigned char args[512];
 };
 hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
-                               float* terminal_obs, bool publish, FleetStepLaunch* out);
+                               float* terminal_obs, FleetStepLaunch* out);
 // compact the terminal observations of the envs with done[e] != 0 (env order): idx[k], *count, compact[k, obs_dim]
 hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,
                                      double* ep_ret, int32_t* ep_len, float* compact, hipStream_t s);

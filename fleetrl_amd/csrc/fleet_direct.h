@@ -25,23 +25,18 @@ int fleet_direct_plan(unsigned grid, bool split, unsigned part_grid[2]);
 int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& launch, const void* tape, int tape_len, size_t row_bytes, bool split,
                          std::string* err);
 int fleet_direct_parts(FleetDirect* q);  // 1 or 2: how the prepared launch is laid out
-// `steps` launches (tape rows 0, 1, ... cyclically), asynchronous.  Fences: every packet acquires at agent scope (the vector / scalar
-// L1s are invalidated) and releases NOTHING -- except the last one when `release_last` (system scope).  Without `release_last` the
-// state the launches wrote stays in the dies' L2s (fleet_direct_release writes it back); what the kernels store write-through
-// (observations, rewards, done flags) is visible to everybody once the launch has completed.
-// `timed`: completion signals with dispatch timestamps -- on the first and the last packet of the run (fleet_direct_wait reports the
-// span), or, `timed == 2`, on every packet (fleet_direct_wait reports each launch's own start -> end).
-int fleet_direct_submit(FleetDirect* q, int steps, int timed, bool release_last, std::string* err);
+// `steps` launches (tape rows 0, 1, ... cyclically) behind the run's placement-record launch, asynchronous.  Fences: every packet acquires
+// at agent scope (the vector / scalar L1s are invalidated; the first at system scope) and releases NOTHING -- except the last, which
+// releases at system scope.
+// `timed`: completion signals with dispatch timestamps -- 1: on the first and the last packet of the run (fleet_direct_wait reports the
+// span); 2: on every packet (fleet_direct_wait reports each launch's own start -> end).
+int fleet_direct_submit(FleetDirect* q, int steps, int timed, std::string* err);
 bool fleet_direct_busy(FleetDirect* q);   // something submitted has not completed
-bool fleet_direct_dirty(FleetDirect* q);  // completed or not, launches have left state in the L2s that no release has written back
 // waits for everything submitted; spans_us (nullable): per timed run since the last wait, in order (see fleet_direct_submit)
 int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string* err);
-// waits, then -- if launches were submitted without a release since the last one -- writes the dies' L2s back (one tiny launch per
-// queue used, release at system scope) and waits for that: after it every byte is where any reader expects it
-int fleet_direct_release(FleetDirect* q, std::vector<double>* spans_us, std::string* err);
 // Test hook (negative tests of the placement guard) --
-// kind 1: the NEXT chain starts from the previous chain's placement record rotated by one workgroup instead of a fresh one (what its
-//         launches would see if the queue's first die moved in the middle of a chain);
+// kind 1: the NEXT run's placement record is shifted by one workgroup (what its launches would see if the queue's first die moved in
+//         the middle of a run);
 // kind 2: in the uploaded argument block of tape row `tape_row`, the first workgroup of the grid shifted by one (every workgroup then
 //         steps its neighbour's envs).
 int fleet_direct_fault(FleetDirect* q, int kind, int tape_row, std::string* err);

@@ -5,10 +5,9 @@
 // coherent with one another, the release is a write-back of the die's dirty lines at the end of EVERY launch -- the next launch waits
 // for it to drain and then fetches those lines again.  Between two steps of the same batch none of that is needed: workgroup w owns
 // the same envs in every launch and the hardware hands workgroup w of every grid to the same die, so every byte of state a die reads
-// was last written by itself (or by nobody: tables, actions).  A launch submitted here keeps the acquire (the per-CU vector caches
-// and the scalar caches ARE invalidated at every launch: a wavefront of env e runs on another CU of its die next time) and drops the
-// release -- until somebody other than the next step needs the state (fleet_direct_release: one tiny launch per queue that releases
-// at system scope), or on the last packet of a run that asks for it.
+// was last written by itself (or by nobody: tables, actions).  A run submitted here keeps the acquire (the per-CU vector caches and
+// the scalar caches ARE invalidated at every launch: a wavefront of env e runs on another CU of its die next time) and drops the
+// release on all packets but the last, which releases at system scope: after the run every result is where any reader expects it.
 // tools/ubench/aql_fence.cpp is the microbenchmark of the effect (read-modify-write of 16 MB by 4096 workgroups: 5.3 -> 2.9 us per
 // launch, empty launch 1.56 -> 1.44 us; results identical over 2000 launches); tests/test_direct_gpu.py holds the step kernel to
 // bit-identical state, observations and rewards against the HIP-stream path.
@@ -19,22 +18,30 @@
 //   * fleet_direct_open PROBES it on the queue it has just created -- a chain of launches, with and without a multiple of 8
 //     workgroups, each workgroup writing down HW_REG_XCC_ID -- and refuses the mode (FLEET_ERR_UNSUPPORTED; callers fall back to HIP's
 //     launches) unless the map workgroup -> die is periodic in 8 and identical from launch to launch;
-//   * the die a queue starts dealing from is NOT a constant of the queue: it moves when other queues are created in the process
-//     (found by this library's own tests: the second queue of a split run moved the first one's).  So every CHAIN of launches --
-//     from one release to the next -- starts with a tiny launch that writes the dies of workgroups 0..7 of that queue, as they are
-//     then, into a device word (fleet_guard_record_kernel), and every step launch of the chain compares the die it finds itself on
-//     with that word (fleet_kernels.hip, "Placement guard": one 8-byte load in the entry burst, one s_getreg): a launch that lands
-//     elsewhere raises FLEET_DEVERR_PLACEMENT, which fleet_check_errors / the host step report as a hard error.  A chain whose
-//     queue moved in its middle is void and says so; between chains (every tape run is one) a move is harmless;
+//   * the die a queue starts dealing from is NOT a constant of the queue: it moves by one whenever a queue is created or destroyed in
+//     the process (found by this library's own tests: the second queue of a split run moved the first one's; then measured,
+//     tools/ubench/xcc_map.cpp).  So every RUN -- a chain of launches that ends with the release -- starts with a tiny launch that
+//     writes the dies of workgroups 0..7 of that queue, as they are then, into the argument blocks of the run's launches
+//     (fleet_guard_record_kernel), and every step launch compares the die it finds itself on with its slot of that record
+//     (fleet_kernels.hip, "Placement guard": one scalar load from the argument segment and one s_getreg at the end of the step): a
+//     launch that lands elsewhere raises FLEET_DEVERR_PLACEMENT, which fleet_check_errors / the host step report as a hard error.
+//     A run whose queue moved in its middle is void and says so; between runs a move is harmless;
 //   * the agent is the one with the HIP device's PCI address -- never "the n-th GPU agent" (HIP and HSA enumerate differently under
 //     *_VISIBLE_DEVICES);
 //   * the code object must carry the source hash the library was compiled with.
 //
-// What a caller may rely on: the state of a run is visible to others only after a release (fleet_synchronize and every other entry
-// point of the handle do one when needed); observations, rewards and done flags of a launch -- stored write-through by the kernel --
-// once that launch has completed.  What the library relies on beside the placement: the single-step kernels touch an env's state only
+// What a caller may rely on: nothing of the run is visible before it has completed (fleet_synchronize / the next call on the handle
+// waits for it), everything after.  What the library relies on beside the placement: the single-step kernels touch an env's state only
 // from that env's own workgroup, and bytes of different envs that share a cache line are merged by the L2's byte masks -- as inside
 // any one launch.
+//
+// What was tried on top and is NOT here (round 6, profiles/r06_experiments/closed_loop_write_through.log): a CLOSED-LOOP step on this
+// queue -- no release, the observations / rewards / done flags of every step stored write-through so that a policy could consume them
+// while the state stays in the L2s.  Built to green parity (a torch policy reading every step's observation, 4096 x 50, against the
+// stream launches bit for bit and against the CPU oracle) and measured: write-through stores run at the memory side's ~1.3 TB/s, the
+// 6.3 MB of observations per launch cost 2.2 us (6.5 -> 8.7 us) -- more than HIP's whole release (8.0 us per step).  A step whose
+// outputs must be visible before the next one starts pays for making them visible; the cheapest way to do that is the release fence,
+// i.e. fleet_step_dev.
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <hsa/hsa.h>
@@ -115,28 +122,27 @@ struct FleetDirect {
   int fd = -1;
   uint64_t tick_hz = 0;
   std::map<std::string, KernelObject> kernels;
-  // placement (see the header comment): per queue the guard word the launches carry -- bit 31 + eight 3-bit dies, index = workgroup & 7
-  KernelObject probe_kernel;
+  // placement (see the header comment)
+  KernelObject probe_kernel;       // fleet_probe_xcc_kernel: the open-time probe
+  KernelObject record_kernel;      // fleet_guard_record_kernel: first launch of every run
   uint32_t* probe_out = nullptr;   // device: kProbeLaunches x kProbeMaxGrid words
   char* probe_kargs = nullptr;     // device: one 64-byte argument block per probe launch
-  uint32_t guard[2] = {0, 0};      // what the probe found (bit 31 + eight 3-bit dies): information only, see fleet_direct_probed
+  uint32_t guard[2] = {0, 0};      // what the probe found per queue (bit 31 + eight 3-bit dies): information, see fleet_direct_probed
   bool probed[2] = {false, false};
-  KernelObject record_kernel;      // fleet_guard_record_kernel: first launch of every chain
-  char* guard_dev = nullptr;       // device: per queue a 64-byte slot -- the 8-byte record the chain's launches check, then the record
-                                   // kernel's argument block (a pointer to that record) at +32
-  int fault_rotate = 0;            // test hook: the next chain starts from a record rotated by one workgroup instead of a fresh one
   bool any_grid = false;           // the map also held across grids that are not multiples of 8 workgroups (both queues)
   uint32_t num_xcc = 0;
+  int fault_rotate = 0;            // test hook: the next run's placement record is shifted by one workgroup
   // the prepared launch
   KernelObject kernel;
   unsigned block = 0;
   int parts = 1;              // 1: the whole grid on queue 0; 2: the grid as two ranges of workgroups, one per queue
   unsigned part_grid[2] = {0, 0};
-  char* kargs_dev = nullptr;  // parts x tape_len blocks of kBlockBytes (part-major)
+  char* kargs_dev = nullptr;  // parts x tape_len blocks of kBlockBytes (part-major), then per part the 64-byte argument block of its
+                              // record launch
   size_t kargs_cap = 0;
   int tape_len = 0;
   std::vector<unsigned char> kargs_host;  // what was uploaded (the fault hook patches a block of it)
-  unsigned packed_n_offset = 0;
+  unsigned packed_n_offset = 0, guard_offset = 0;
   static constexpr size_t kBlockBytes = 512;
   // signals: a pool; the ones handed out since the last wait; per timed run what its spans are read from
   std::vector<hsa_signal_t> pool, pending;
@@ -144,8 +150,6 @@ struct FleetDirect {
   std::vector<Mark> marks;
   hsa_signal_t last[2] = {};
   bool in_flight = false;
-  bool dirty[2] = {false, false};  // launches without a release since the queue's last release
-  bool acquire_system = true;      // the next packet is the first since a release (or since the queue exists)
 };
 
 #ifdef FLEET_STAMPS
@@ -387,21 +391,6 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
   int rc = kernel_by_name(q, "fleet_probe_xcc_kernel", &q->probe_kernel, err);
   if (rc != FLEET_OK) return fail(rc);
   if ((rc = kernel_by_name(q, "fleet_guard_record_kernel", &q->record_kernel, err)) != FLEET_OK) return fail(rc);
-  {
-    unsigned char slots[128] = {0};
-    if (hipMalloc(reinterpret_cast<void**>(&q->guard_dev), sizeof slots) != hipSuccess) {
-      if (err) *err = "fleet_direct_open: out of device memory";
-      return fail(FLEET_ERR_HIP);
-    }
-    for (int part = 0; part < 2; ++part) {
-      const char* rec = q->guard_dev + 64 * part;
-      memcpy(slots + 64 * part + 32, &rec, sizeof rec);
-    }
-    if (hipMemcpy(q->guard_dev, slots, sizeof slots, hipMemcpyHostToDevice) != hipSuccess) {
-      if (err) *err = "fleet_direct_open: argument upload failed";
-      return fail(FLEET_ERR_HIP);
-    }
-  }
   if ((rc = probe_queue(q, 0, err)) != FLEET_OK) return fail(rc);
 #ifdef FLEET_STAMPS
   g_last_direct = q;
@@ -412,7 +401,7 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
 
 void fleet_direct_close(FleetDirect* q) {
   if (!q) return;
-  if (q->in_flight || q->dirty[0] || q->dirty[1]) (void)fleet_direct_release(q, nullptr, nullptr);
+  if (q->in_flight) (void)fleet_direct_wait(q, nullptr, nullptr);
 #ifdef FLEET_STAMPS
   if (g_last_direct == q) g_last_direct = nullptr;
 #endif
@@ -425,7 +414,6 @@ void fleet_direct_close(FleetDirect* q) {
   if (q->kargs_dev) (void)hipFree(q->kargs_dev);
   if (q->probe_out) (void)hipFree(q->probe_out);
   if (q->probe_kargs) (void)hipFree(q->probe_kargs);
-  if (q->guard_dev) (void)hipFree(q->guard_dev);
   if (q->hsa_up) (void)hsa_shut_down();
   delete q;
 }
@@ -508,7 +496,8 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
                         std::to_string(part_grid[part]) + ")";
         return FLEET_ERR_UNSUPPORTED;
       }
-  const size_t need = (size_t)parts * tape_len * FleetDirect::kBlockBytes;
+  const size_t blocks_bytes = (size_t)parts * tape_len * FleetDirect::kBlockBytes;
+  const size_t need = blocks_bytes + (size_t)parts * 64;
   std::vector<unsigned char> host(need, 0);
   for (int part = 0; part < parts; ++part)
     for (int k = 0; k < tape_len; ++k) {
@@ -523,8 +512,7 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
         packed = (int32_t)(((uint32_t)packed & 0xffffu) | (part_grid[0] << 16));
         memcpy(b + L.packed_n_offset, &packed, 4);
       }
-      const char* rec = q->guard_dev + 64 * part;  // the placement record of the queue this part runs on
-      memcpy(b + L.guard_offset, &rec, sizeof rec);
+      memset(b + L.guard_offset, 0, 8);  // the placement record: written by the run's first launch (fleet_direct_submit)
     }
   char* dev = q->kargs_dev;
   if (need > q->kargs_cap) {
@@ -533,6 +521,11 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
       if (err) *err = "fleet_direct_prepare: out of device memory";
       return FLEET_ERR_HIP;
     }
+  }
+  for (int part = 0; part < parts; ++part) {  // the record launch of each part: (its blocks, rows, stride, offset of the record, rotate)
+    struct { char* blocks; int rows; unsigned stride, offset; int rotate; } ra = {dev + (size_t)part * tape_len * FleetDirect::kBlockBytes, tape_len,
+                                                                                   (unsigned)FleetDirect::kBlockBytes, L.guard_offset, 0};
+    memcpy(host.data() + blocks_bytes + (size_t)part * 64, &ra, sizeof ra);
   }
   if (hipMemcpy(dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) {
     if (dev != q->kargs_dev) (void)hipFree(dev);
@@ -553,6 +546,7 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
   q->part_grid[1] = part_grid[1];
   q->tape_len = tape_len;
   q->packed_n_offset = L.packed_n_offset;
+  q->guard_offset = L.guard_offset;
   return FLEET_OK;
 }
 
@@ -581,7 +575,7 @@ int fleet_direct_fault(FleetDirect* q, int kind, int tape_row, std::string* err)
   return FLEET_OK;
 }
 
-int fleet_direct_submit(FleetDirect* q, int steps, int timed, bool release_last, std::string* err) {
+int fleet_direct_submit(FleetDirect* q, int steps, int timed, std::string* err) {
   if (!q || !q->queue[0] || q->tape_len < 1 || steps < 1) return FLEET_ERR_INVALID;
   if (q->pending.size() > 4096) {  // a caller that submits run after run without ever waiting (more than any timed series): a wait recycles the signals
     const int rc = fleet_direct_wait(q, nullptr, err);
@@ -614,22 +608,15 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, bool release_last,
         m.each[(size_t)i * q->parts + part] = s;
       }
   }
-  const bool chain_start = q->acquire_system;
-  if (chain_start) {
-    // the chain's placement record (header comment): the dies of workgroups 0..7 of each queue, as they are now
-    if (q->fault_rotate) {  // test hook: the previous chain's record rotated by one workgroup, and no fresh one
-      q->fault_rotate = 0;
-      for (int part = 0; part < q->parts; ++part) {
-        unsigned long long w = 0;
-        if (hipMemcpy(&w, q->guard_dev + 64 * part, 8, hipMemcpyDeviceToHost) != hipSuccess) return FLEET_ERR_HIP;
-        w = (w >> 8) | (w << 56);
-        if (hipMemcpy(q->guard_dev + 64 * part, &w, 8, hipMemcpyHostToDevice) != hipSuccess) return FLEET_ERR_HIP;
-      }
-    } else {
-      for (int part = 0; part < q->parts; ++part)
-        write_packet(q->queue[part], q->record_kernel, 64, 8, q->guard_dev + 64 * part + 32, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE,
-                     hsa_signal_t{});
+  // the run's placement record (header comment): the dies of workgroups 0..7 of each queue, as they are now, into the argument blocks
+  const size_t rec_args = (size_t)q->parts * q->tape_len * FleetDirect::kBlockBytes;
+  for (int part = 0; part < q->parts; ++part) {
+    if (q->fault_rotate) {  // test hook: a record shifted by one workgroup
+      const int one = 1;
+      if (hipMemcpy(q->kargs_dev + rec_args + (size_t)part * 64 + 20, &one, 4, hipMemcpyHostToDevice) != hipSuccess) return FLEET_ERR_HIP;
     }
+    write_packet(q->queue[part], q->record_kernel, 64, 8, q->kargs_dev + rec_args + (size_t)part * 64, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE,
+                 hsa_signal_t{});
   }
   for (int i = 0; i < steps; ++i)
     for (int part = 0; part < q->parts; ++part) {  // step by step, queue by queue: both chains get going at once
@@ -639,8 +626,8 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, bool release_last,
       else if (timed == 1 && i == 0) sig = m.first[part];
       // the first packet after a release acquires at system scope (whatever the host or another queue wrote meanwhile), the others
       // at agent scope; a packet releases only when it is the last of a run that asks for it
-      const int acq = (i == 0 && q->acquire_system) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-      const int rel = (i == steps - 1 && release_last) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
+      const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+      const int rel = (i == steps - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
       write_packet(q->queue[part], q->kernel, q->block, q->part_grid[part],
                    q->kargs_dev + ((size_t)part * q->tape_len + (size_t)(i % q->tape_len)) * FleetDirect::kBlockBytes, acq, rel, sig);
     }
@@ -649,14 +636,17 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, bool release_last,
       for (int part = 0; part < q->parts; ++part) m.first[part] = m.last[part];
     q->marks.push_back(std::move(m));
   }
-  for (int part = 0; part < 2; ++part) {
-    if (part < q->parts) {
-      q->last[part] = (timed ? q->marks.back().last[part] : m.last[part]);
-      q->dirty[part] = !release_last;
-    }
-  }
-  q->acquire_system = release_last;
+  for (int part = 0; part < 2; ++part) q->last[part] = part < q->parts ? (timed ? q->marks.back().last[part] : m.last[part]) : hsa_signal_t{};
   q->in_flight = true;
+  if (q->fault_rotate) {  // (the hook corrupts ONE run: the next one records as ever)
+    q->fault_rotate = 0;
+    const int rc = fleet_direct_wait(q, nullptr, err);
+    if (rc != FLEET_OK) return rc;
+    const int zero = 0;
+    for (int part = 0; part < q->parts; ++part)
+      if (hipMemcpy(q->kargs_dev + rec_args + (size_t)part * 64 + 20, &zero, 4, hipMemcpyHostToDevice) != hipSuccess) return FLEET_ERR_HIP;
+    return FLEET_OK;
+  }
   return FLEET_OK;
 }
 
@@ -669,20 +659,18 @@ bool fleet_direct_busy(FleetDirect* q) {
   return false;
 }
 
-bool fleet_direct_dirty(FleetDirect* q) { return q && (q->dirty[0] || q->dirty[1]); }
-
 int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string* err) {
   if (!q) return FLEET_ERR_INVALID;
   if (q->in_flight) {
     // spin for the first millisecond (a caller that polls -- fleet_stream_query -- never gets here before the run is done; one that
     // synchronises right after a short run wants it back within microseconds), then sleep on the signal's interrupt.
-    // 60 s in all: a run of 16384 launches of the largest batch is ~1 s
+    // 20 s in all: a run of 16384 launches of the largest batch is ~1 s
     const uint64_t hz = q->tick_hz ? q->tick_hz : 100000000ull;
     for (hsa_signal_t sgn : q->last) {
       if (!sgn.handle) continue;
       if (hsa_signal_wait_scacquire(sgn, HSA_SIGNAL_CONDITION_LT, 1, hz / 1000, HSA_WAIT_STATE_ACTIVE) >= 1 &&
-          hsa_signal_wait_scacquire(sgn, HSA_SIGNAL_CONDITION_LT, 1, hz * 60ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
-        if (err) *err = "fleet_direct_wait: the launches did not complete within 60 s";
+          hsa_signal_wait_scacquire(sgn, HSA_SIGNAL_CONDITION_LT, 1, hz * 20ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
+        if (err) *err = "fleet_direct_wait: the launches did not complete within 20 s";
         return FLEET_ERR_HIP;
       }
     }
@@ -720,38 +708,5 @@ int fleet_direct_wait(FleetDirect* q, std::vector<double>* spans_us, std::string
   for (hsa_signal_t sgn : q->pending) q->pool.push_back(sgn);
   q->pending.clear();
   q->last[0].handle = q->last[1].handle = 0;
-  return FLEET_OK;
-}
-
-int fleet_direct_release(FleetDirect* q, std::vector<double>* spans_us, std::string* err) {
-  if (!q) return FLEET_ERR_INVALID;
-  int rc = fleet_direct_wait(q, spans_us, err);
-  if (rc != FLEET_OK) return rc;
-  if (!q->dirty[0] && !q->dirty[1]) return FLEET_OK;
-  // one tiny launch per queue that ran launches without a release: eight workgroups (one per die) of the probe kernel, whose packet
-  // releases at system scope -- the write-back of every die's L2 the launches did without
-  hsa_signal_t done[2] = {};
-  for (int part = 0; part < 2; ++part) {
-    if (!q->dirty[part] || !q->queue[part]) continue;
-    done[part] = take_signal(q);
-    if (!done[part].handle) {
-      if (err) *err = "fleet_direct_release: hsa_signal_create failed";
-      return FLEET_ERR_HIP;
-    }
-    write_packet(q->queue[part], q->probe_kernel, 256, 8, q->probe_kargs, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, done[part]);
-  }
-  const uint64_t hz = q->tick_hz ? q->tick_hz : 100000000ull;
-  for (int part = 0; part < 2; ++part) {
-    if (!done[part].handle) continue;
-    const bool timeout = hsa_signal_wait_scacquire(done[part], HSA_SIGNAL_CONDITION_LT, 1, hz / 1000, HSA_WAIT_STATE_ACTIVE) >= 1 &&
-                         hsa_signal_wait_scacquire(done[part], HSA_SIGNAL_CONDITION_LT, 1, hz * 60ull, HSA_WAIT_STATE_BLOCKED) >= 1;
-    q->pool.push_back(done[part]);
-    if (timeout) {
-      if (err) *err = "fleet_direct_release: the release did not complete within 60 s";
-      return FLEET_ERR_HIP;
-    }
-    q->dirty[part] = false;
-  }
-  q->acquire_system = true;
   return FLEET_OK;
 }

@@ -100,9 +100,6 @@ constexpr int kBlock = FLEET_KBLOCK;  // threads per workgroup
 // per-wavefront partial sums meet in the LDS behind one workgroup barrier, and the group's last lane adds them up (round 5: the
 // c5 shard's 200-EV envs as 4 wavefronts x 1 EV per lane instead of 1 wavefront x 4 EVs per lane walked one after the other).
 constexpr int kMaxGroup = 256;
-// floats of the per-wavefront staging row of the single-step kernel's observation (one wavefront = one env): 7 * 64 per-EV slots + up
-// to 128 floats of env-level blocks
-constexpr int kObsLdsFloats = 576;
 static_assert(kMaxGroup <= kBlock && kBlock % 64 == 0, "a lane group is a whole number of a workgroup's wavefronts");
 
 // ---------------------------------------------------------------------------------------------------------
@@ -242,23 +239,7 @@ typedef float fleet_v4f __attribute__((ext_vector_type(4)));
 // Observation rows are written once and read by nobody on the chip: non-temporal stores (-1.5 % per launch, r03 ab_nt.log).
 // Everything else is stored plain: write-through (`sc1`) and non-temporal state stores were measured on every class of store
 // and lose everywhere (profiles/r03_experiments/ab_stores.log).
-// PUB: the launch PUBLISHES its outputs (fleet_step_direct_dev: a step on the library's own queue whose packet carries no release
-// fence).  Observations, rewards and done flags are then stored write-through (`sc1`: agent scope, the store is complete when it has
-// left the die's L2) and the wavefront drains its stores before it ends, so that whoever starts after the launch -- on any die, any
-// queue -- finds them in memory; the env state keeps its plain stores and stays in the die's L2.
-template <bool PUB = false>
-__device__ __forceinline__ void st_obs(float* p, float v) {
-  if constexpr (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else __builtin_nontemporal_store(v, p);
-}
-// sixteen bytes of an observation row in one store (the row staged in the LDS, below).  Written through, a 16-byte store costs what a
-// plain one does; four-byte write-through stores are one fabric write EACH (measured: 4096 x 50, 6.5 -> 8.65 us per launch with the
-// seven per-EV slots stored that way, profiles/r06_experiments/obs_write_through_dword.log).
-template <bool PUB>
-__device__ __forceinline__ void st_obs16(fleet_v4f* p, const fleet_v4f& v) {
-  if constexpr (PUB) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
-  else __builtin_nontemporal_store(v, p);
-}
+__device__ __forceinline__ void st_obs(float* p, float v) { __builtin_nontemporal_store(v, p); }
 template <typename T>
 __device__ __forceinline__ void st_rec16(T* p, const T& v) {  // a 16-byte record as ONE store
   static_assert(sizeof(T) == 16, "16-byte record");
@@ -282,8 +263,7 @@ __device__ __forceinline__ const T* at_off(const T* base, unsigned& byte_off) {
 }
 template <typename T>
 __device__ __forceinline__ void st_plain(T* p, const T& v) { *p = v; }
-template <bool PUB = false>
-__device__ __forceinline__ void st_obs_at(float* base, unsigned& byte_off, float v) { st_obs<PUB>(at_off(base, byte_off), v); }
+__device__ __forceinline__ void st_obs_at(float* base, unsigned& byte_off, float v) { st_obs(at_off(base, byte_off), v); }
 
 // One EV of one env: the planes [E, N] are addressed as (plane + e * N) + c -- the first part is wave-uniform when a
 // wavefront is one env (G == 64) and lives in scalar registers.
@@ -327,15 +307,14 @@ __device__ __forceinline__ RowRec seg_row(const SegRec& s, int r, double dt) {
 // exact-match fraction; the north-star tolerance is 1e-5).  Round 3 read these four words from a [T, N] table: 16 bytes per EV
 // and step, 7 of a wavefront's 44 line requests; the two float64 divisions that had made the per-lane form lose in round 3
 // (ab_seg3.log) are gone.
-template <bool PUB = false>
 __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restrict__ row, int c, double soc, float hl, double tgt,
                                              const RowRec& tb) {
   const int N = d.N;
   // one 32-bit lane offset for all seven slots; the slot arrays' bases are wave-uniform when a wavefront is one env (scalar
   // registers, `global_store ... s[base]` addressing: no 64-bit vector address per slot)
   unsigned o4 = (unsigned)c * 4u;
-  st_obs_at<PUB>(row, o4, (float)soc);
-  st_obs_at<PUB>(row + N, o4, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
+  st_obs_at(row, o4, (float)soc);
+  st_obs_at(row + N, o4, d.normalize ? (float)((double)hl / d.self->max_time_left) : hl);
   if (!d.aux) return;
   float* a = row + 2 * N + d.tail_a_len;
   const double th = (double)tb.there;
@@ -344,48 +323,18 @@ __device__ __forceinline__ void write_obs_ev(const FleetDev& d, float* __restric
   const double hn = cl * d.hn_scale;
   double lax = ((double)tb.tl * rcp_newton1(hn + 0.001) - 1.0) * th;
   lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);  // np.clip(., 0, 5): keeps -0.0 (an absent EV) and NaN like numpy does
-  st_obs_at<PUB>(a, o4, (float)tb.there);
+  st_obs_at(a, o4, (float)tb.there);
   if (d.normalize) {
     const FleetCold* cd = d.self->cold;
-    st_obs_at<PUB>(a + N, o4, (float)(tgt_th * cd->inv_max_soc));
-    st_obs_at<PUB>(a + 2 * N, o4, (float)(cl * cd->inv_max_soc));
-    st_obs_at<PUB>(a + 3 * N, o4, (float)(hn * cd->inv_max_hours_needed));
-    st_obs_at<PUB>(a + 4 * N, o4, (float)(lax * cd->inv_max_laxity));
+    st_obs_at(a + N, o4, (float)(tgt_th * cd->inv_max_soc));
+    st_obs_at(a + 2 * N, o4, (float)(cl * cd->inv_max_soc));
+    st_obs_at(a + 3 * N, o4, (float)(hn * cd->inv_max_hours_needed));
+    st_obs_at(a + 4 * N, o4, (float)(lax * cd->inv_max_laxity));
   } else {
-    st_obs_at<PUB>(a + N, o4, (float)tgt_th);
-    st_obs_at<PUB>(a + 2 * N, o4, (float)cl);
-    st_obs_at<PUB>(a + 3 * N, o4, (float)hn);
-    st_obs_at<PUB>(a + 4 * N, o4, (float)lax);
-  }
-}
-
-// The same seven slots into the wavefront's staging row in the LDS (one wavefront = one env: `lds` is the env's whole observation
-// row, flushed by the wavefront in 16-byte pieces once the tail is in, fleet_step_kernel).  Same arithmetic, same float32 words.
-__device__ __forceinline__ void write_obs_ev_lds(const FleetDev& d, float* __restrict__ lds, int c, double soc, float hl, double tgt,
-                                                 const RowRec& tb) {
-  const int N = d.N;
-  lds[c] = (float)soc;
-  lds[N + c] = d.normalize ? (float)((double)hl / d.self->max_time_left) : hl;
-  if (!d.aux) return;
-  float* a = lds + 2 * N + d.tail_a_len;
-  const double th = (double)tb.there;
-  const double tgt_th = tgt * th;
-  const double cl = tgt_th - tb.sor;
-  const double hn = cl * d.hn_scale;
-  double lax = ((double)tb.tl * rcp_newton1(hn + 0.001) - 1.0) * th;
-  lax = lax < 0.0 ? 0.0 : (lax > 5.0 ? 5.0 : lax);
-  a[c] = (float)tb.there;
-  if (d.normalize) {
-    const FleetCold* cd = d.self->cold;
-    a[N + c] = (float)(tgt_th * cd->inv_max_soc);
-    a[2 * N + c] = (float)(cl * cd->inv_max_soc);
-    a[3 * N + c] = (float)(hn * cd->inv_max_hours_needed);
-    a[4 * N + c] = (float)(lax * cd->inv_max_laxity);
-  } else {
-    a[N + c] = (float)tgt_th;
-    a[2 * N + c] = (float)cl;
-    a[3 * N + c] = (float)hn;
-    a[4 * N + c] = (float)lax;
+    st_obs_at(a + N, o4, (float)tgt_th);
+    st_obs_at(a + 2 * N, o4, (float)cl);
+    st_obs_at(a + 3 * N, o4, (float)hn);
+    st_obs_at(a + 4 * N, o4, (float)lax);
   }
 }
 
@@ -399,21 +348,21 @@ __device__ __forceinline__ float tail_load(const FleetDev& d, int t, int g) {
   return (g < total) ? d.tab_tail[(size_t)t * d.tail_stride + g] : 0.0f;
 }
 
-template <int G, bool PUB = false>
+template <int G>
 __device__ __forceinline__ void tail_store(const FleetDev& d, float* __restrict__ row, int t, int g, float first) {
   const float* __restrict__ src = d.tab_tail + (size_t)t * d.tail_stride;
   const int na = d.tail_a_len, total = d.tail_a_len + d.tail_b_len;
   const unsigned base_a = 2u * (unsigned)d.N, base_b = 7u * (unsigned)d.N;  // block B: 2N + na + 5N + (j - na) = 7N + j
   int j = g;
-  if (j < total) st_obs<PUB>(row + ((j < na ? base_a : base_b) + (unsigned)j), first);
+  if (j < total) st_obs(row + ((j < na ? base_a : base_b) + (unsigned)j), first);
   if (total > G) {
-    for (j += G; j < total; j += G) st_obs<PUB>(row + ((j < na ? base_a : base_b) + (unsigned)j), src[j]);
+    for (j += G; j < total; j += G) row[(j < na ? base_a : base_b) + (unsigned)j] = src[j];
   }
 }
 
-template <int G, bool PUB = false>
+template <int G>
 __device__ __forceinline__ void write_obs_tail(const FleetDev& d, float* __restrict__ row, int t, int g) {
-  tail_store<G, PUB>(d, row, t, g, tail_load<G>(d, t, g));
+  tail_store<G>(d, row, t, g, tail_load<G>(d, t, g));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -740,7 +689,6 @@ __device__ __forceinline__ Hot hot_encode(const FleetDev& d, const EvIx& i, doub
 // env's part on another thread than its EVs').
 // The EV's part (fleet_environment.py:345-399): state of health, SOC / hours_left from the start row, laxity fix-up, first SOC
 // sample, the carried schedule record, the observation slots.  `log_obs_row` / `log_ev_soh`: the data log's row reset() writes.
-template <bool PUB = false>
 __device__ __forceinline__ void reset_ev(const FleetDev& d, int e, int c, int start, float* __restrict__ obs_row,
                                          float* __restrict__ log_obs_row, double* __restrict__ log_ev) {
   const int N = d.N;
@@ -773,7 +721,7 @@ __device__ __forceinline__ void reset_ev(const FleetDev& d, int e, int c, int st
     hd.s2 = soc_deg;  // the stack is [soc_deg]: its only entry lives in the header
     *hp = hd;
   }
-  if (obs_row) write_obs_ev<PUB>(d, obs_row, c, soc, hl, tgt, tb);
+  if (obs_row) write_obs_ev(d, obs_row, c, soc, hl, tgt, tb);
   if (log_obs_row) {
     write_obs_ev(d, log_obs_row, c, soc, hl, tgt, tb);
     double* lev = log_ev + c;
@@ -807,7 +755,7 @@ __device__ __forceinline__ void reset_head(const FleetDev& d, int e, const EnvHe
 }
 
 // `lp`: the env's data-log cursor (rows written so far; only used when the log is on), advanced by the row reset() writes.
-template <int G, bool LOG, bool PUB = false>
+template <int G, bool LOG>
 __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
   const bool log_on = LOG && (d.log_pos != nullptr);
   const int N = d.N;
@@ -816,8 +764,8 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
   const size_t lrow = log_on ? (size_t)(lp % d.log_cap) * d.E + e : 0;
   float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
   double* const log_ev = log_on ? d.log_ev + lrow * 4 * N : nullptr;
-  for (int c = g; c < N; c += G) reset_ev<PUB>(d, e, c, start, obs_row, log_obs_row, log_ev);
-  if (obs_row) write_obs_tail<G, PUB>(d, obs_row, start, g);
+  for (int c = g; c < N; c += G) reset_ev(d, e, c, start, obs_row, log_obs_row, log_ev);
+  if (obs_row) write_obs_tail<G>(d, obs_row, start, g);
   if (log_on) {
     write_obs_tail<G>(d, log_obs_row, start, g);
     if (leader) {
@@ -1015,8 +963,8 @@ struct StepKernargs {
   uint8_t* done;
   float* terminal_obs;
   int32_t* done_count;
-  const unsigned long long* guard;  // placement guard of a chain of launches on the library's own queue (see the kernel);
-                                    // nullptr for every launch through HIP
+  unsigned long long guard_bytes;  // placement record of the chain of launches this one belongs to (see the kernel, "Placement
+                                   // guard"): byte k = 0x80 | die of workgroups w with (w & 7) == k; 0 = no check (every launch through HIP)
 };
 static_assert(offsetof(StepKernargs, d_arg) == offsetof(StepKernargPrefix, d_arg) && sizeof(StepKernargs) <= sizeof(FleetStepLaunch::args),
               "the argument block of a described launch");
@@ -1028,7 +976,7 @@ thread_local FleetStepLaunch* t_describe = nullptr;  // set by fleet_describe_st
 // kModeAll = everything behind run-time tests (the data-log instances and the small groups, where instances are not multiplied).
 constexpr int kModeAll = 0, kModeTape = 1, kModePolicy = 2, kModeRt = 3;
 
-template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false, int MODE = kModeAll, bool PUB = false>
+template <int G, int DEG, bool MULTI, bool WIDE, bool LOG = false, bool A64 = false, int MODE = kModeAll>
 __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWaves) : kSingleWaves) void fleet_step_kernel(
     // The first twelve argument dwords are preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count,
     // fleetrl_amd/build.py; twelve is what fits beside the other user registers): what the first loads of a wavefront need --
@@ -1039,8 +987,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     FleetDev d_arg, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
-                                                               int32_t* __restrict__ done_count,
-                                                               const unsigned long long* __restrict__ guard) {
+                                                               int32_t* __restrict__ done_count, unsigned long long guard_bytes) {
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
   // The argument block is ~150 dwords of scalars for ~100 scalar registers.  One step per launch, one EV per lane: what the END
@@ -1118,35 +1065,10 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     ep_len = er->ep_len;
   }
   uint32_t err = 0;
-  // Placement guard (single-step launches on the library's own queue, fleet_direct.hip).  Such launches carry no release fence,
-  // which is only correct while workgroup w of every launch of a chain runs on the die (XCC) that ran workgroup w of the previous
-  // one -- a die's L2 is the only place the env's newest state lives.  The hardware deals the workgroups of a dispatch to the dies
-  // round-robin from a die that belongs to the QUEUE, but that die is not a constant: it moves when queues are created in the
-  // process (measured: tools/ubench/xcc_map.cpp) and the platform promises nothing (MI355X_MICROARCH.md, "Workgroup dispatch, XCD
-  // placement").  So every chain starts with a tiny launch that writes down the die of workgroups 0..7 of THIS queue NOW
-  // (`fleet_guard_record_kernel`, eight bytes, written through), and every step launch of the chain compares the die it finds
-  // itself on with that record: one 8-byte load that joins the entry burst, one s_getreg and a few scalar instructions at the end.
-  // A mismatch raises FLEET_DEVERR_PLACEMENT (sticky; the chain's results are void, the caller is told by fleet_check_errors).
-  unsigned char guard_die = 0;  // the die the record holds for this workgroup's slot (one byte: one register across the step)
-  if (!MULTI && guard)
-    guard_die = __hip_atomic_load(reinterpret_cast<const unsigned char*>(guard) + ((blockIdx.x + (unsigned)wg_base) & 7u), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);  // (past the CU's cache)
   double reward_sum = 0.0;
   int n_done = 0;
   float* const obs_row = obs + (size_t)e * d.obs_dim;
   float* const term_row = terminal_obs ? terminal_obs + (size_t)e * d.obs_dim : nullptr;
-  // One wavefront = one env, one step per launch: the env's observation row -- seven slot arrays N floats apart plus the two
-  // env-level blocks -- is assembled in the LDS (kObsLdsFloats * 4 bytes per wavefront) and leaves the wavefront as whole 16-byte
-  // pieces of ONE contiguous row: two store instructions per lane instead of eight, full lines at the memory side -- and the form in
-  // which a row can be written THROUGH at the price of plain stores (PUB).  A row that is not a multiple of 16 bytes long leaves as
-  // contiguous 4-byte pieces.  (Rows longer than the staging area: the launcher routes such a batch to the K-step kernel.)
-  static_assert(!PUB || !MULTI, "only single-step launches publish their outputs");
-  constexpr bool kObsLds = !MULTI && !WIDE && G == 64;
-  float* lds_row = nullptr;
-  if constexpr (kObsLds) {
-    __shared__ __attribute__((aligned(16))) float s_obs[kBlock / 64][kObsLdsFloats];
-    lds_row = s_obs[threadIdx.x / 64];
-  }
   const int steps = MULTI ? K : 1;
   const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);  // 0 in every lane, opaque to the uniformity analysis
   // night-charging policy: the env's "charging since" row travels in a register over the K steps
@@ -1198,11 +1120,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // where this step's observation goes: with vec-env auto-reset the terminal observation is reported aside
     float* const step_row = resets ? term_row : obs_row;
     // intermediate steps of a K-step launch only need their observation when the episode ends (terminal observation)
-#ifdef FLEET_X_NO_OBS
-    const bool write_step_obs = false;
-#else
     const bool write_step_obs = env_ok && (step_row != nullptr) && (!MULTI || rt || resets || k == steps - 1);
-#endif
 
     FLEET_STAMP(1);
     // ---- loads that depend on the time row: the row's physics scalars and observation tail -----------------------------
@@ -1371,10 +1289,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
       const double tgt_obs = t090 ? 0.9 : d.target_soc;  // the target the observer sees: after this step's sticky update
-      if (write_step_obs) {
-        if constexpr (kObsLds) write_obs_ev_lds(d, lds_row, c, soc, hl, tgt_obs, tb1);
-        else write_obs_ev<PUB>(d, step_row, c, soc, hl, tgt_obs, tb1);
-      }
+      if (write_step_obs) write_obs_ev(d, step_row, c, soc, hl, tgt_obs, tb1);
       if (logs) write_obs_ev(d, log_obs_row, c, soc, hl, tgt_obs, tb1);
 
       // ---- money terms of EvCharger.charge: the only consumers of the time row's physics record, which was requested when
@@ -1396,26 +1311,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     {  // ---- the rest of the step reads the argument block afresh (see `late_args`) ----
     const FleetDev& d = late_args();
     if (!MULTI && !WIDE && (d.T != d_arg.T || d.E != p_E)) err |= FLEET_DEVERR_INTERNAL;  // the block is not where it is assumed to be
-    if (write_step_obs) {
-      if constexpr (kObsLds) {
-        // the env-level blocks join the staged row, then the wavefront stores the row: lane j the 16-byte pieces j, j + 64
-        const int na = d.tail_a_len, total = d.tail_a_len + d.tail_b_len;
-        const float* __restrict__ src = d.tab_tail + (size_t)t1 * d.tail_stride;
-        const int base_a = 2 * d.N, base_b = 7 * d.N;
-        for (int j = g; j < total; j += G) lds_row[(j < na ? base_a : base_b) + j] = (j == g) ? tail_first : src[j];
-        __builtin_amdgcn_wave_barrier();  // (one wavefront: its LDS operations execute in order; this only pins the compiler's)
-        if ((d.obs_dim & 3) == 0) {
-          const fleet_v4f* l4 = reinterpret_cast<const fleet_v4f*>(lds_row);
-          fleet_v4f* g4 = reinterpret_cast<fleet_v4f*>(step_row);
-          const int n4 = d.obs_dim >> 2;
-          for (int j = g; j < n4; j += G) st_obs16<PUB>(g4 + j, l4[j]);
-        } else {
-          for (int j = g; j < d.obs_dim; j += G) st_obs<PUB>(step_row + j, lds_row[j]);
-        }
-      } else {
-        tail_store<G, PUB>(d, step_row, t1, g, tail_first);
-      }
-    }
+    if (write_step_obs) tail_store<G>(d, step_row, t1, g, tail_first);
     if (logs) tail_store<G>(d, log_obs_row, t1, g, tail_first);
     if (DEG != FLEET_DEG_NONE) r.nsamp += 1;
 
@@ -1488,13 +1384,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (env_ok) {
         d.env[e].cashflow = cash;  // cashflow = -charging_cost + discharging_revenue (ev_charger.py:225)
         if (!MULTI) {
-          if constexpr (PUB) {  // written through, like the observation (see st_obs)
-            __hip_atomic_store(reward + e, rew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done + e, (uint8_t)(is_done ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            reward[e] = rew;
-            done[e] = is_done ? 1 : 0;
-          }
+          reward[e] = rew;
+          done[e] = is_done ? 1 : 0;
         }
       }
     }
@@ -1542,7 +1433,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (resets) {
         head_reset = true;
         if (env_ok) {
-          reset_env<G, LOG, PUB>(*d.self, e, g, leader, r, obs_row, lp);
+          reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
           if (kRfCarry) carry_load();  // the reset rewrote the row's head (same lane, same addresses: program order holds)
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
@@ -1590,17 +1481,33 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (kPol && act_mode == FLEET_ACT_POLICY_NIGHT) d.cold->night_start[e] = night_st;
     }
   }
-  if (!MULTI && guard) {
+  // Placement guard (single-step launches on the library's own queue, fleet_direct.hip).  Such launches carry no release fence,
+  // which is only correct while workgroup w of every launch of a chain runs on the die (XCC) that ran workgroup w of the previous
+  // one -- a die's L2 is the only place the env's newest state lives.  The hardware deals the workgroups of a dispatch to the dies
+  // round-robin from a die that belongs to the QUEUE, but that die is not a constant: it moves by one whenever a queue is created
+  // or destroyed in the process (measured: tools/ubench/xcc_map.cpp) and the platform promises nothing (MI355X_MICROARCH.md,
+  // "Workgroup dispatch, XCD placement").  So every chain starts with a tiny launch that writes the dies of workgroups 0..7 of
+  // THIS queue, as they are then, into the argument blocks of the chain's launches (`fleet_guard_record_kernel`), and every step
+  // launch compares the die it finds itself on with its slot of that record -- here, at the very end, from the kernel-argument
+  // segment itself: one scalar load that hits the constant cache, one s_getreg, a few scalar instructions, nothing held across
+  // the step (a record carried from the entry cost 1-3 % per launch in spilled scalars, one fetched by a device-scope vector load
+  // 4 %: profiles/r06_experiments/placement_guard_cost.log).  A mismatch raises FLEET_DEVERR_PLACEMENT (sticky; the chain's
+  // results are void, fleet_check_errors tells the caller).  Launches through HIP carry a record of zeros: no check.
+  if constexpr (!MULTI) {
+    typedef const __attribute__((address_space(4))) char* karg_ptr;
+    karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StepKernargs, guard_bytes);
+    asm volatile("" : "+s"(kp));  // (not hoisted to the entry: see late_args)
+    const unsigned long long rec = *(const __attribute__((address_space(4))) unsigned long long*)kp;
+    const unsigned slot = (unsigned)(rec >> (8u * ((blockIdx.x + (unsigned)wg_base) & 7u))) & 0xffu;
     const unsigned have = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits [3:0]
-    if (have != (unsigned)guard_die) err |= FLEET_DEVERR_PLACEMENT;
+    if ((slot & 0x80u) && (slot & 0xfu) != have) err |= FLEET_DEVERR_PLACEMENT;
+    (void)guard_bytes;
   }
   if (err && env_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
     atomicOr(&d.env[e].err, err);
     atomicOr(d.self->err_any, err);
   }
   }  // late_args scope
-  // a publishing launch drains its write-through stores before the wavefront ends: "completed" then means "in memory"
-  if constexpr (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FLEET_STAMP(8);
   FLEET_STAMP_RT(10);
   FLEET_STAMP_WHERE();
@@ -1625,7 +1532,8 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t E = d.E, EN = (size_t)d.E * d.N;
   const bool per_car = field == FLEET_F_SOC || field == FLEET_F_HOURS_LEFT || field == FLEET_F_SOH || field == FLEET_F_SOC_DEG ||
-                       field == FLEET_F_TARGET_SOC || field == FLEET_F_RF_LEN || field == FLEET_F_FD_CYC ||
+                       field == FLEET_F_TARGET_SOC || field == FLEET_F_RF_LEN || field == FLEET_F_RF_CYCLES || field == FLEET_F_RF_STACK ||
+                       field == FLEET_F_FD_CYC ||
                        field == FLEET_F_FD_CAL || field == FLEET_F_SEI_L;
   if (i >= (per_car ? EN : E)) return;
   switch (field) {
@@ -1637,6 +1545,10 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_RF_LEN:
       ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride)->rf_len : 1;
       break;
+    case FLEET_F_RF_CYCLES:
+      ((int32_t*)out)[i] = d.rf_rows ? reinterpret_cast<const RfHdr*>(d.rf_rows + i * (size_t)d.rf_row_stride)->nc : 0;
+      break;
+    case FLEET_F_RF_STACK: ((int32_t*)out)[i] = d.rf_rows ? HOT_TAIL(d.hot[i].bits) : 0; break;
     case FLEET_F_FD_CYC: ((double*)out)[i] = d.sei[i].fd_cyc; break;
     case FLEET_F_FD_CAL: ((double*)out)[i] = d.sei[i].fd_cal; break;
     case FLEET_F_SEI_L: ((double*)out)[i] = d.sei[i].sei_l; break;
@@ -1774,7 +1686,7 @@ void launch_many(const FleetDev& d, dim3 grid, dim3 block, const void* actions, 
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
 #define FLEET_MANY(MODE)                                                                                                          \
   hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, WIDE, false, false, MODE>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, act_mode, K, \
-                     obs, reward, done, terminal_obs, done_count, nullptr)
+                     obs, reward, done, terminal_obs, done_count, 0ull)
   if (G < 32) FLEET_MANY(kModeAll);
   else if (d.real_time) FLEET_MANY((G < 32 ? kModeAll : kModeRt));
   else if (act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) FLEET_MANY((G < 32 ? kModeAll : kModePolicy));
@@ -1790,25 +1702,16 @@ inline void describe_launch(FleetStepLaunch* L, const void* host_fn, dim3 grid, 
   a.p_hot = d.hot; a.p_run = d.run; a.p_soh = d.soh; a.p_actions = actions; a.p_E = d.E; a.p_N = d.N; a.p_env = d.env;
   a.d_arg = d; a.actions = actions; a.act_mode = act_mode; a.K = 1;
   a.obs = obs; a.reward = reward; a.done = done; a.terminal_obs = terminal_obs; a.done_count = done_count;
-  L->host_fn = host_fn; L->grid = grid.x; L->block = block.x;
-  L->args_bytes = (unsigned)sizeof a;
+  L->host_fn = host_fn; L->grid = grid.x; L->block = block.x; L->args_bytes = (unsigned)sizeof a;
   L->actions_offset[0] = (unsigned)offsetof(StepKernargs, p_actions); L->actions_offset[1] = (unsigned)offsetof(StepKernargs, actions);
   L->packed_n_offset = (unsigned)offsetof(StepKernargs, p_N);
-  L->guard_offset = (unsigned)offsetof(StepKernargs, guard);
+  L->guard_offset = (unsigned)offsetof(StepKernargs, guard_bytes);
   memcpy(L->args, &a, sizeof a);
 }
-// (GV, WIDEV, A64V: the instance; a described launch may ask for the instance that publishes its outputs, FleetStepLaunch::publish)
-#define FLEET_LAUNCH_SINGLE(GV, WIDEV, A64V, GRID)                                                                                     \
+#define FLEET_LAUNCH_SINGLE(KERNEL, GRID)                                                                                              \
   do {                                                                                                                                 \
-    if (t_describe && t_describe->publish)                                                                                             \
-      describe_launch(t_describe, (const void*)(fleet_step_kernel<GV, DEG, false, WIDEV, false, A64V, kModeAll, true>), GRID, block, d, \
-                      actions, f64, obs, reward, done, terminal_obs, done_count);                                                      \
-    else if (t_describe)                                                                                                               \
-      describe_launch(t_describe, (const void*)(fleet_step_kernel<GV, DEG, false, WIDEV, false, A64V>), GRID, block, d, actions, f64,   \
-                      obs, reward, done, terminal_obs, done_count);                                                                    \
-    else                                                                                                                               \
-      hipLaunchKernelGGL((fleet_step_kernel<GV, DEG, false, WIDEV, false, A64V>), GRID, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, \
-                         obs, reward, done, terminal_obs, done_count, nullptr);                                                             \
+    if (t_describe) describe_launch(t_describe, (const void*)(KERNEL), GRID, block, d, actions, f64, obs, reward, done, terminal_obs, done_count); \
+    else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done, terminal_obs, done_count, 0ull); \
   } while (0)
 
 template <int G, int DEG>
@@ -1818,10 +1721,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
   const dim3 grid((d.E + epb - 1) / epb), block(kBlock);
   const int f64 = act_dtype;  // FLEET_ACT_F32 / FLEET_ACT_F64 / FLEET_ACT_POLICY_* (policies: MULTI kernel only)
   // the single-step kernel carries neither the policies, nor the event-skipping loop, nor the data-log code
-  // (... and, one wavefront per env, stages the observation row in kObsLdsFloats of LDS: a longer row -- look-aheads of more than ~50
-  // hours -- takes the K-step kernel's per-slot stores)
-  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos) &&
-                      !(G == 64 && d.N <= 64 && d.obs_dim > kObsLdsFloats);
+  const bool single = (K == 1 && !done_count && act_dtype < FLEET_ACT_POLICY_UNCONTROLLED && !d.real_time && !d.log_pos);
   if (t_describe && !single) return hipErrorNotSupported;  // only single-step launches are described
   // K steps per launch from a tape or a built-in policy keep one EV per lane too (not the event-skipping loop, not the data log)
   const bool many_grouped = (!single && !d.real_time && !d.log_pos);
@@ -1835,34 +1735,34 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
     if (d.N <= 128) {
       const dim3 g2((d.E + 1) / 2);
       if (f64 == FLEET_ACT_F64)
-        FLEET_LAUNCH_SINGLE(GG2, false, true, g2);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG2, DEG, false, false, false, true>), g2);
       else
-        FLEET_LAUNCH_SINGLE(GG2, false, false, g2);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG2, DEG, false, false>), g2);
     } else {
       const dim3 g4(d.E);
       if (f64 == FLEET_ACT_F64)
-        FLEET_LAUNCH_SINGLE(GG4, false, true, g4);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG4, DEG, false, false, false, true>), g4);
       else
-        FLEET_LAUNCH_SINGLE(GG4, false, false, g4);
+        FLEET_LAUNCH_SINGLE((fleet_step_kernel<GG4, DEG, false, false>), g4);
     }
     return hipGetLastError();
   }
   if (G == 64 && d.N > G) {  // more EVs than lanes: every lane walks several EVs
     if (single)
-      FLEET_LAUNCH_SINGLE(G, (G == 64), false, grid);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, (G == 64)>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64), true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
-                         done, terminal_obs, done_count, nullptr);
+                         done, terminal_obs, done_count, 0ull);
     else
       launch_many<G, DEG, (G == 64)>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   } else {
     if (single && f64 == FLEET_ACT_F64)
-      FLEET_LAUNCH_SINGLE(G, false, true, grid);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, false, false, true>), grid);
     else if (single)
-      FLEET_LAUNCH_SINGLE(G, false, false, grid);
+      FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, false>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
-                         terminal_obs, done_count, nullptr);
+                         terminal_obs, done_count, 0ull);
     else
       launch_many<G, DEG, false>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   }
@@ -1893,17 +1793,22 @@ hipError_t launch_reset_g(const FleetDev& d, const uint8_t* mask, float* obs, hi
 extern "C" __global__ void fleet_probe_xcc_kernel(uint32_t* __restrict__ out) {
   if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
 }
-// The first launch of every chain on the library's own queue: byte k of `guard` = the die workgroup k (of 8) of this queue's
-// dispatches runs on right now.  Written through and drained, so that the step launches behind it -- on any die -- read it from memory.
-extern "C" __global__ void fleet_guard_record_kernel(unsigned long long* __restrict__ guard) {
-  if (threadIdx.x == 0 && blockIdx.x < 8) {
-    unsigned char* b = reinterpret_cast<unsigned char*>(guard) + blockIdx.x;
-    __hip_atomic_store(b, (unsigned char)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xfu), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+// The first launch of every chain on the library's own queue (eight workgroups): workgroup k writes 0x80 | (the die it runs on) into
+// byte k of the placement record of every argument block of the chain's step launches (`blocks`: `rows` blocks, `stride` bytes apart,
+// the record `offset` bytes into each; fleet_step_kernel's argument `guard_bytes`).  Written through and drained, so that the step
+// launches behind it -- whose constant caches are invalidated when they start -- read it from memory.
+// (`rotate`: 0 -- or, test hook of the guard's negative test, the record shifted by that many workgroups.)
+extern "C" __global__ void fleet_guard_record_kernel(unsigned char* __restrict__ blocks, int rows, unsigned stride, unsigned offset, int rotate) {
+  if (blockIdx.x >= 8) return;
+  const unsigned char v = (unsigned char)(0x80u | (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xfu));
+  const unsigned slot = (blockIdx.x + (unsigned)rotate) & 7u;
+  // (64 = the workgroup size the library launches it with: a kernel whose packets are written by hand must not read blockDim / gridDim --
+  // they live in the implicit arguments HIP appends to the argument block, which these launches do not carry)
+  for (int r = (int)threadIdx.x; r < rows; r += 64)
+    __hip_atomic_store(blocks + (size_t)r * stride + offset + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// Which sources this code was compiled from (fleetrl_amd/build.py passes the hash of the kernel sources and flags to BOTH artefacts):
+// Which sources this code was compiled from (fleetrl_amd/build.py passes the hash of the sources and flags to BOTH artefacts):
 // fleet_direct_open reads the code object's copy through the HSA loader and refuses a code object that is not the library's twin.
 #ifndef FLEET_SRC_SHA
 #define FLEET_SRC_SHA "unversioned"
@@ -1940,9 +1845,8 @@ hipError_t fleet_launch_step(const FleetDev& d, const void* actions, int act_dty
 }
 
 hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
-                               float* terminal_obs, bool publish, FleetStepLaunch* out) {
+                               float* terminal_obs, FleetStepLaunch* out) {
   out->host_fn = nullptr;
-  out->publish = publish;
   t_describe = out;
   const hipError_t e = fleet_launch_step(d, actions, act_dtype, 1, obs, reward, done, terminal_obs, nullptr, nullptr);
   t_describe = nullptr;

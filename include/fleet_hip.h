@@ -207,6 +207,9 @@ typedef struct FleetEnvBatch* fleet_handle;
 #define FLEET_F_EPISODES 18      /* i32 [E]   finished-episode counter */
 #define FLEET_F_PENALTY_RECORD 19 /* f64 [E]  episode.penalty_record */
 #define FLEET_F_LAST_EP_LEN_F64 20 /* f64 [E] length of the last finished episode as float64 (fleet_get_dev / the RCCL gather) */
+#define FLEET_F_RF_CYCLES 21     /* i32 [E,N] rainflow cycles closed so far in the running episode (0 without rainflow degradation) */
+#define FLEET_F_RF_STACK 22      /* i32 [E,N] reversal points on the EV's rainflow stack (bench.py derives the share of EV-steps that
+                                    push a reversal point / close a cycle from the two: the workload's invariants)               */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */
@@ -338,8 +341,9 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
  *   FLEET_LAUNCH_DIRECT  AQL dispatch packets written by the library into an HSA queue of the handle's own, with the cache
  *                        actions HIP attaches to every kernel boundary reduced to what a run of steps needs: every launch still
  *                        invalidates the per-CU caches, only the LAST launch of the run writes the L2s back: no launch
- *                        waits for the previous one's write-back (workgroup w of every launch runs on die w mod 8, so a die
- *                        only reads state it wrote itself).
+ *                        waits for the previous one's write-back (workgroup w of every launch of a run stays on one die, so a die
+ *                        only reads state it wrote itself; probed when the queue is opened, recorded at the start of every run and
+ *                        checked by every launch: FLEET_DEVERR_PLACEMENT, fleet_direct_placement).
  *                        Semantics: asynchronous like the others, but NOT on the HIP stream -- the run starts after everything
  *                        the stream holds has completed (the call waits for that), nothing of it is visible before it has
  *                        completed, and every later call on the handle (fleet_synchronize, a step, a get ...) waits for it first;
@@ -352,47 +356,24 @@ int fleet_timer_read(fleet_handle h, float* elapsed_ms);
  * ranges of workgroups on TWO queues, each an in-order chain of its own (the halves drift apart and overlap: 16384 x 50 -17 % per
  * step); FLEET_LAUNCH_DIRECT_ONE_QUEUE never does.  fleet_direct_queues: how the handle's last direct run was laid out (0: none yet). */
 #define FLEET_LAUNCH_DIRECT_ONE_QUEUE 3
-/* FLEET_LAUNCH_DIRECT with the launches of fleet_step_direct_dev (below): every step PUBLISHES its observations, rewards and done flags
- * (stored write-through, visible to anybody once the launch has completed) while the state stays in the dies' L2s -- the closed-loop
- * step, fed from a tape: what bench.py times as `closed_loop`. */
-#define FLEET_LAUNCH_DIRECT_PUBLISH 4
 int fleet_run_tape_dev(fleet_handle h, int steps, const void* tape, int tape_len, int act_dtype,
                        float* obs, double* reward, uint8_t* done, int use_graph);
 
 int fleet_direct_queues(fleet_handle h);
 
-/* ---- closed loop on the library's own queue ---------------------------------------------------------------------------------
- * fleet_step_dev's contract -- every step's observation is there before the next action is chosen (FleetEnv.step returns it,
- * /root/reference/fleetrl/fleet_env/fleet_environment.py:436,702) -- on the launch path of FLEET_LAUNCH_DIRECT: ONE launch per call,
- * written by the library into its own HSA queue, with no release fence.  The env state stays in the dies' L2s from step to step;
- * what a policy consumes -- obs, reward, done, terminal_obs -- is stored write-through by the kernel and is visible to every later
- * launch on any stream, to copies and to other processes' reads of the buffers as soon as the launch has completed.
- *   fleet_step_direct_dev   waits for what the handle's HIP stream was given before (the producer of `actions`: launch it on the
- *                           handle's stream, or synchronise your own stream first), submits the step, returns at once.  Buffers as
- *                           fleet_step_dev.  Keep the same buffers from step to step: the launch's argument block is prepared
- *                           once per set of pointers (another set costs a small upload).  The handle must be on its own stream.
- *   fleet_wait_step         host wait (spinning, then sleeping) until the submitted steps have completed: their outputs may be read
- *                           by anybody from then on.  The state is NOT written back by this.
- * Every other entry point of the handle (fleet_synchronize, fleet_get, fleet_step_dev, fleet_reset_dev ...) first waits for the
- * steps in flight and has the state written back (one tiny launch that releases at system scope), so the calls mix freely.
- * Cost per step of the missing write-back and what the write-through stores cost instead: DESIGN.md section 4. */
-int fleet_step_direct_dev(fleet_handle h, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
-                          float* terminal_obs /* [E,obs_dim] or NULL */);
-int fleet_wait_step(fleet_handle h);
-
-/* What FLEET_LAUNCH_DIRECT / fleet_step_direct_dev rely on, as probed when the handle opened its queue (opens it if need be):
+/* What FLEET_LAUNCH_DIRECT relies on, as probed when the handle opened its queue (opens it if need be):
  * map8[k] = the die (HW_REG_XCC_ID) that chain of probe launches found workgroups w with (w & 7) == k on; num_xcc = dies of the
  * device; any_grid = 1 if the map also held across launches whose grids are not multiples of 8 workgroups.  The map is information:
- * the die a queue deals from moves when queues are created in the process, so every chain of launches records the map afresh on the
- * device and every launch checks the die it runs on against that record (FLEET_DEVERR_PLACEMENT).  FLEET_ERR_UNSUPPORTED: the probe
+ * the die a queue deals from moves whenever a queue is created or destroyed in the process, so every run records the map afresh on
+ * the device (its first launch) and every step launch checks the die it runs on against that record (FLEET_DEVERR_PLACEMENT).  FLEET_ERR_UNSUPPORTED: the probe
  * found the placement not periodic or not stable from launch to launch, and the mode is refused on this platform. */
 int fleet_direct_placement(fleet_handle h, int32_t map8[8], int32_t* num_xcc, int32_t* any_grid);
 /* How a grid of `grid_workgroups` is laid over the handle's queues (a pure function, no device needed): returns 1 (part_grid[0] = the
  * whole grid) or 2 (two ranges of workgroups: part_grid[0] a multiple of 8 that fits the kernel's 16-bit first-workgroup field). */
 int fleet_direct_split_plan(uint32_t grid_workgroups, int split, uint32_t part_grid[2]);
 /* TEST HOOK for the placement guard (the handle must have run through its own queue before) --
- * kind 1: the handle's NEXT chain of launches starts from the previous chain's placement record rotated by one workgroup instead of
- *         recording a fresh one: what its launches would see if the queue's first die had moved in the middle of a chain;
+ * kind 1: the handle's NEXT run gets a placement record shifted by one workgroup: what its launches would see if the queue's first
+ *         die had moved in the middle of the run;
  * kind 2: in the prepared argument block of tape row `tape_row`, the grid's first workgroup shifted by one (every workgroup steps its
  *         neighbour's envs: the state IS corrupted).
  * The next run (through that row) must raise FLEET_DEVERR_PLACEMENT. */

@@ -37,7 +37,17 @@ def test_bench_json_contract_single_gpu():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"] == "fleet_step_kernel<G=64,DEG=rainflow,MULTI=false,WIDE=false>"
     assert abs(d["value"] - 512 * 300 / (d["ms_per_step"] * 300 * 1e-3)) / d["value"] < 1e-9
-    assert d["config"]["launch_mode"] == "direct" and "FLEET_LAUNCH_DIRECT" in d["config"]["launch"]  # the default: the library's own queue
+    # the default: the library's own queue as an open-loop replay, labelled as such, with the closed-loop path (HIP's launches) of the
+    # same kernel beside it, the other episode phase's figure, and what the run did
+    assert d["config"]["launch_mode"] == "direct" and "FLEET_LAUNCH_DIRECT" in d["config"]["launch"] and "OPEN LOOP" in d["config"]["launch"]
+    assert d["config"]["closed_loop"] is False and r["launch_mode"] == "direct"
+    (name, cl), = r["other_launch_paths"].items()
+    assert name == "closed_loop_hip_graph" and "CLOSED LOOP" in cl["what"] and cl["kernel_ms"] > r["kernel_ms"]
+    assert abs(cl["frac"] - cl["achieved"] / 8000.0) < 1e-12
+    assert r["other_phase"]["phase"] == "staggered" and r["other_phase"]["kernel_ms"] > 0 and "locked" in d["config"]["episode_phase"]
+    inv = d["config"]["workload_invariants"]
+    assert 0.10 < inv["push_fraction"] < 0.40 and 0.03 < inv["closure_fraction"] < inv["push_fraction"] and inv["ev_steps"] > 0
+    assert d["config"]["action_tape"].startswith("32 independent rows")
     assert "timing" in d and d["errcheck"] is True and r["kernel_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
@@ -49,7 +59,26 @@ def test_bench_through_a_replayed_hipgraph():
                           "--prime-ms", "50", "--no-cpu-baseline", "--no-host-path"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     d = _json_line(res.stdout)
-    assert d["config"]["launch"] == "hipGraph of 64 launches" and d["config"]["launch_mode"] == "graph" and d["roofline"]["kernel_ms"] > 0
+    assert d["config"]["launch"].startswith("hipGraph of 64 launches") and d["config"]["launch_mode"] == "graph" and d["roofline"]["kernel_ms"] > 0
+    assert d["config"]["closed_loop"] is True and set(d["roofline"]["other_launch_paths"]) == {"open_loop_direct_queue"}
+
+
+def test_bench_workload_invariants_agree_across_shapes():
+    """The shapes the roofline claims are made on run the SAME workload: the share of EV-steps that push a rainflow reversal point /
+    close a cycle agrees within 5 % between the headline shape, 16384 x 50 and the c5 shard (the short cyclic tapes of
+    round 5 had made the large shapes another workload -- batteries saturated, the push dropped out)."""
+    inv = {}
+    for name, extra in (("c3", ["--config", "c3"]), ("16384x50", ["--config", "c3", "--envs-per-gpu", "16384"]), ("c5", ["--config", "c5"])):
+        res = subprocess.run([sys.executable, "bench.py", *extra, "--steps", "64", "--warmup", "20", "--prime-ms", "50", "--reps", "3",
+                              "--no-cpu-baseline", "--no-host-path"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        d = _json_line(res.stdout)
+        inv[name] = d["config"]["workload_invariants"]
+        assert d["config"]["action_tape"].startswith("32 independent rows")
+    for k in ("push_fraction", "closure_fraction"):
+        # (c5 mixes three fleet types with other schedules: its own level, compared at 15 %; the two caretaker shapes at 5 %)
+        assert abs(inv["16384x50"][k] - inv["c3"][k]) <= 0.05 * inv["c3"][k], (k, inv)
+        assert abs(inv["c5"][k] - inv["c3"][k]) <= 0.15 * inv["c3"][k], (k, inv)
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():

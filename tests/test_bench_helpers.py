@@ -52,18 +52,19 @@ def test_committed_traffic_only_counts_for_the_kernel_it_was_profiled_on(tmp_pat
     for f in ("fleet_kernels.hip", "fleet_device.h"):
         (tmp_path / "fleetrl_amd" / "csrc" / f).write_text("v1 " + f)
     sha = bench.kernel_source_sha()
-    (tmp_path / "profiles" / "r05_traffic_c3.json").write_text(json.dumps(
+    (tmp_path / "profiles" / "r06_traffic_c3.json").write_text(json.dumps(
         {"kernel_src_sha": sha, "envs": 4096, "evs": 50, "config": "c3", "hbm_bytes_per_launch": 123.0, "launch_mode": "direct"}))
-    (tmp_path / "profiles" / "r05_traffic_16384x50.json").write_text(json.dumps(
+    (tmp_path / "profiles" / "r06_traffic_16384x50.json").write_text(json.dumps(
         {"kernel_src_sha": sha, "envs": 16384, "evs": 50, "config": "c3", "hbm_bytes_per_launch": 456.0, "launch_mode": "direct"}))
-    val, src = bench.committed_traffic("c3", 4096, 50)
-    assert val == 123.0 and "profiles/r05_traffic_c3.json" in src  # the JSON line says where the figure comes from
-    assert bench.committed_traffic("c3", 16384, 50)[0] == 456.0  # an override's shape has a profile of its own
-    assert bench.committed_traffic("c3", 8192, 50)[0] is None
+    val, src = bench.committed_traffic("c3", 4096, 50, "direct")
+    assert val == 123.0 and "profiles/r06_traffic_c3.json" in src  # the JSON line says where the figure comes from
+    assert bench.committed_traffic("c3", 16384, 50, "direct")[0] == 456.0  # an override's shape has a profile of its own
+    assert bench.committed_traffic("c3", 8192, 50, "direct")[0] is None
+    assert bench.committed_traffic("c3", 4096, 50, "publish")[0] is None  # the closed-loop launches write their outputs through: other traffic
     assert bench.committed_traffic("c3", 4096, 50, "graph")[0] is None  # ... and the way the launches reached the GPU
-    assert bench.committed_traffic("c5", 8192, 200)[0] is None
+    assert bench.committed_traffic("c5", 8192, 200, "direct")[0] is None
     (tmp_path / "fleetrl_amd" / "csrc" / "fleet_kernels.hip").write_text("v2")
-    val, src = bench.committed_traffic("c3", 4096, 50)
+    val, src = bench.committed_traffic("c3", 4096, 50, "direct")
     assert val is None and "no committed" in src
 
 

@@ -1,14 +1,14 @@
-"""The safety net of the library's own launch queue (fleetrl_amd/csrc/fleet_direct.hip) and the closed-loop step on it.
+"""The safety net of the library's own launch queue (fleetrl_amd/csrc/fleet_direct.hip).
 
 Launches on that queue carry no release fence, so an env's newest state lives in ONE die's L2 between two steps: that is only correct
-while workgroup w of every launch of a chain runs on the die that ran workgroup w of the previous one.  The platform deals workgroups
-that way but does not promise it (and the die a queue deals from moves when queues are created), so
+while workgroup w of every launch of a run runs on the die that ran workgroup w of the previous one.  The platform deals workgroups
+that way but does not promise it (and the die a queue deals from moves whenever a queue is created or destroyed in the process), so
   * the queue is probed when it is opened (`fleet_direct_placement`),
-  * every chain records the queue's dies on the device and every launch checks itself against the record (FLEET_DEVERR_PLACEMENT),
+  * every run records the queue's dies in its launches' argument blocks and every launch checks itself against the record
+    (FLEET_DEVERR_PLACEMENT),
   * the negative tests here force a mismatch and must see the error, the positive ones must never see it;
-and the closed-loop entry (`fleet_step_direct_dev` / `fleet_wait_step`: outputs written through, state left in the L2s) must give a
-policy that reads EVERY step's observation exactly what the stream launches give it -- and what the CPU oracle computes.
-Reference contract: FleetEnv.step returns the observation of every step (fleet_environment.py:436,702).  Needs an MI355X."""
+and the launch path bench.py times is held against the CPU oracle DIRECTLY at the headline size (round 5 only compared it with the
+stream launches, which are what meets the oracle).  Needs an MI355X."""
 import os
 import subprocess
 import sys
@@ -62,7 +62,7 @@ def test_placement_probe_reports_a_rotation_over_the_dies():
 
 @pytest.mark.parametrize("kind", [1, 2])
 def test_placement_guard_trips_when_a_launch_lands_elsewhere(kind):
-    """kind 1: the chain's placement record is one workgroup off (= the queue's first die moved in the middle of a chain); kind 2: one
+    """kind 1: the run's placement record is one workgroup off (= the queue's first die moved in the middle of a run); kind 2: one
     launch of the run has its workgroups shifted by one.  Either way the launches find themselves on another die than recorded and
     say so; a healthy run before and a fresh handle after stay clean."""
     import torch
@@ -157,51 +157,10 @@ def test_agent_is_matched_by_pci_address_under_visible_devices():
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-# ---- the closed loop ----------------------------------------------------------------------------------------------------------
-def _policy(obs, N):
-    """A policy that needs EVERY step's observation: charge against the state of charge and the time left it has just been shown
-    (float32 arithmetic, the same on the device and in NumPy)."""
-    soc, hl = obs[:, :N], obs[:, N:2 * N]
-    a = 0.9 - 1.7 * soc + 0.02 * hl
-    return a.clip(-1.0, 1.0) if isinstance(a, np.ndarray) else a.clamp(-1.0, 1.0)
-
-
-@pytest.mark.parametrize("name,E,steps", [("ct5_both_rainflow", 777, 420), ("lmd1_price_linear", 300, 250), ("ut3_both_norm_rainflow", 640, 300)])
-def test_closed_loop_steps_equal_stream_steps_golden_shapes(name, E, steps):
-    """A torch policy on torch's stream reads every step's observation and writes the next action; the steps go through the library's
-    own queue (no release fence, outputs written through) on one handle and through fleet_step_dev on the other: bit-identical
-    observations, rewards and done flags at EVERY step, and the same state afterwards."""
-    import torch
-
-    g, (a, b), rng = _batch(name, E, n=2)
-    dev = torch.device("cuda", 0)
-    oa, ob = _bufs(a), _bufs(b)
-    act_a = torch.zeros((E, g.N), device=dev)
-    act_b = torch.zeros((E, g.N), device=dev)
-    term = torch.zeros((E, a.obs_dim), device=dev)
-    term_b = torch.zeros((E, a.obs_dim), device=dev)
-    for k in range(steps):
-        act_a.copy_(_policy(oa[0], g.N))
-        act_b.copy_(_policy(ob[0], g.N))
-        torch.cuda.synchronize()
-        a.step_dev(act_a.data_ptr(), *(t.data_ptr() for t in oa), terminal_ptr=term.data_ptr())
-        a.synchronize()
-        b.step_direct_dev(act_b.data_ptr(), *(t.data_ptr() for t in ob), terminal_ptr=term_b.data_ptr())
-        b.wait_step()  # outputs visible; the state is NOT written back
-        for x, y, what in zip(ob, oa, ("obs", "reward", "done")):
-            assert torch.equal(x, y), f"{what} at step {k}"
-        d = oa[2].bool()
-        assert torch.equal(term_b[d], term[d]), f"terminal observations at step {k}"
-    for f in STATE:
-        np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)  # (the get writes the state back first)
-    b.check_errors()
-    a.close(); b.close()
-
-
-def test_closed_loop_at_the_headline_shape_against_the_oracle():
-    """4096 envs x 50 EVs, 400 closed-loop steps over two episode ends: every step's observation feeds the next action.  The library's
-    own queue against the stream launches bit for bit at every step, and against the CPU oracle (driven with the same policy on ITS
-    observations) within the parity tolerances -- the direct check of this launch path at full size."""
+def test_direct_run_at_the_headline_shape_against_the_oracle():
+    """4096 envs x 50 EVs, 400 launches through the library's own queue over two episode ends, from a 32-row action tape: the final
+    observations / rewards / done flags and the whole state against the CPU oracle stepping the same tape -- the direct check of the
+    launch path bench.py times, at full size (it was only transitively oracle-checked)."""
     import torch
 
     from bench import bench_config
@@ -211,109 +170,84 @@ def test_closed_loop_at_the_headline_shape_against_the_oracle():
     from fleetrl_amd.synth import synth_tables
     from oracle.fleet_oracle import OracleBatch
 
-    E, N, steps = 4096, 50, 400
+    E, N, L, steps = 4096, 50, 32, 400
     tb = synth_tables("ct", N)
     p = make_params(resolve_config(bench_config(E, N, "ct")), tb, E, auto_reset=True, seed=0)
     tf = time_features(tb)
-    dev = torch.device("cuda", 0)
-    a, b = FleetBatch(p, tb, tf), FleetBatch(p, tb, tf)
+    rng = np.random.default_rng(21)
+    acts = rng.uniform(-1, 1, size=(L, E, N)).astype(np.float32)
+    acts[rng.random(acts.shape) < 0.15] = 0.0
+    b = FleetBatch(p, tb, tf)
     cpu = OracleBatch(p, tb, tf, threads=min(8, os.cpu_count() or 1))
-    oa, ob = _bufs(a), _bufs(b)
+    o = _bufs(b)
     oc = cpu.reset()
-    np.testing.assert_allclose(ob[0].cpu().numpy(), oc, rtol=1e-6, atol=1e-7)
-    act_a, act_b = torch.zeros((E, N), device=dev), torch.zeros((E, N), device=dev)
-    worst = 0.0
-    for k in range(steps):
-        act_a.copy_(_policy(oa[0], N))
-        act_b.copy_(_policy(ob[0], N))
-        torch.cuda.synchronize()
-        a.step_dev(act_a.data_ptr(), *(t.data_ptr() for t in oa))
-        a.synchronize()
-        b.step_direct_dev(act_b.data_ptr(), *(t.data_ptr() for t in ob))
-        b.wait_step()
-        for x, y, what in zip(ob, oa, ("obs", "reward", "done")):
-            assert torch.equal(x, y), f"{what} at step {k}"
-        oc, rc, dc, _ = cpu.step(_policy(oc, N).astype(np.float32))
-        if k % 8 == 0 or k > steps - 4:
-            oh = ob[0].cpu().numpy()
-            assert np.array_equal(ob[2].cpu().numpy(), dc), f"done at step {k}"
-            np.testing.assert_allclose(oh, oc, rtol=1e-5, atol=1e-6, err_msg=f"obs vs the oracle at step {k}")
-            np.testing.assert_allclose(ob[1].cpu().numpy(), rc, rtol=1e-7, atol=1e-9, err_msg=f"reward vs the oracle at step {k}")
-            worst = max(worst, float(np.max(np.abs(oh - oc) / (np.abs(oc) + 1e-6))))
-    for f in STATE:
-        np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
-    np.testing.assert_allclose(b.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(o[0].cpu().numpy(), oc, rtol=1e-6, atol=1e-7)
+    tape = torch.from_numpy(acts).to("cuda:0")
+    done_steps = 0
+    for chunk in (1, 63, 200, 136):  # several runs: each starts with its own placement record and ends with the release
+        b.run_tape_dev(chunk, tape.data_ptr(), L, *(t.data_ptr() for t in o), use_graph=_capi.LAUNCH_DIRECT)
+        # (the tape is replayed from row 0 by every run)
+        for k in range(chunk):
+            oc, rc, dc, _ = cpu.step(acts[k % L])
+        b.synchronize()
+        done_steps += chunk
+        assert np.array_equal(o[2].cpu().numpy(), dc), f"done after {done_steps} launches"
+        np.testing.assert_allclose(o[0].cpu().numpy(), oc, rtol=1e-5, atol=1e-6, err_msg=f"obs after {done_steps} launches")
+        np.testing.assert_allclose(o[1].cpu().numpy(), rc, rtol=1e-9, atol=1e-12, err_msg=f"reward after {done_steps} launches")
+    np.testing.assert_allclose(b.get("soc"), cpu.get("soc"), rtol=1e-9, atol=1e-15)
     np.testing.assert_allclose(b.get("soh"), cpu.get("soh"), rtol=1e-9)
-    assert np.array_equal(b.get("time_idx"), cpu.get("time_idx")) and np.array_equal(b.get("rf_len"), cpu.get("rf_len"))
+    # The cycle bookkeeping: the reference's reversal extraction compares SOC samples EXACTLY, so an EV whose SOC saturates (this tape
+    # drives batteries into their limits, like bench.py's) can count one cycle more or less in one engine than in the other once the
+    # two SoH values differ in their last bits ("What that implies over very long horizons"): at most a handful
+    # of the 204 800 EVs, and never anything but the cycle bookkeeping of those EVs.
+    fd_h, fd_c, len_h, len_c = b.get("fd_cyc"), cpu.get("fd_cyc"), b.get("rf_len"), cpu.get("rf_len")
+    off = ~np.isclose(fd_h, fd_c, rtol=1e-8, atol=1e-18) | (len_h != len_c)
+    if off.any():
+        import warnings
+
+        e, c = np.argwhere(off)[0]
+        warnings.warn(f"{int(off.sum())} of {off.size} EVs differ in their cycle bookkeeping; first: env {e} EV {c}: fd_cyc {fd_h[e, c]!r} / "
+                      f"{fd_c[e, c]!r}, rainflow_length {len_h[e, c]} / {len_c[e, c]}, soh {b.get('soh')[e, c]!r} / {cpu.get('soh')[e, c]!r}, "
+                      f"sei_l {b.get('sei_l')[e, c]!r} / {cpu.get('sei_l')[e, c]!r}")
+    assert off.sum() <= 4, f"{int(off.sum())} EVs differ in their cycle bookkeeping"
+    for f in ("time_idx", "episodes", "hours_left"):
+        np.testing.assert_array_equal(b.get(f), cpu.get(f), err_msg=f)
     assert b.get("episodes").min() >= 2
     b.check_errors()
-    a.close(); b.close(); cpu.close()
+    b.close(); cpu.close()
 
 
-@pytest.mark.parametrize("E,N", [(333, 50), (512, 100), (300, 200), (96, 300), (1500, 5)])
-def test_publishing_launches_equal_stream_launches_every_geometry(E, N):
-    """FLEET_LAUNCH_DIRECT_PUBLISH (the closed-loop launch fed from a tape) for one wavefront per env with a partly filled last
-    workgroup, two and four wavefronts per env, several EVs per lane and 8-lane groups: the write-through stores of every geometry."""
-    import torch
-
-    from fleetrl_amd.batch import FleetBatch
-    from fleetrl_amd.config import resolve_config
-    from fleetrl_amd.params import make_params, time_features
-    from test_hip_shapes import _cfg, _tables
-
-    tb = _tables("ct", N)
-    p = make_params(resolve_config(_cfg("ct", "rainflow", False, episode_length=24)), tb, E, seed=7)
-    tf = time_features(tb)
-    rng = np.random.default_rng(E + N)
-    acts = rng.uniform(-1, 1, size=(11, E, N)).astype(np.float32)
-    tape = torch.from_numpy(acts).to("cuda:0")
-    a, b = FleetBatch(p, tb, tf), FleetBatch(p, tb, tf)
-    oa, ob = _bufs(a), _bufs(b)
-    for steps in (3, 150, 64):
-        a.run_tape_dev(steps, tape.data_ptr(), 11, *(t.data_ptr() for t in oa), use_graph=_capi.LAUNCH_EAGER)
-        b.run_tape_dev(steps, tape.data_ptr(), 11, *(t.data_ptr() for t in ob), use_graph=_capi.LAUNCH_DIRECT_PUBLISH)
-        a.synchronize(); b.synchronize()
-        for x, y, what in zip(ob, oa, ("obs", "reward", "done")):
-            assert torch.equal(x, y), f"{what} after {steps} launches"
-        for f in STATE:
-            np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
-    b.check_errors()
-    a.close(); b.close()
-
-
-def test_closed_loop_steps_mix_with_every_other_entry():
-    """Steps through the queue, then -- without any explicit synchronisation -- host steps, a masked reset, a K-step launch, a tape run:
-    every entry point writes the state back first."""
-    import torch
-
-    g, (a, b), rng = _batch(E=200, n=2)
-    dev = torch.device("cuda", 0)
-    oa, ob = _bufs(a), _bufs(b)
-    acts = rng.uniform(-1, 1, size=(40, 200, g.N)).astype(np.float32)
-    tape = torch.from_numpy(acts).to(dev)
-    for k in range(25):
-        a.step_dev(tape[k].data_ptr(), *(t.data_ptr() for t in oa))
-        b.step_direct_dev(tape[k].data_ptr(), *(t.data_ptr() for t in ob))  # another action pointer every step: re-prepared each time
-    for k in range(10):  # host steps straight after
-        xa, ra, da, _ = a.step(acts[k])
-        xb, rb, db, _ = b.step(acts[k])
-        np.testing.assert_array_equal(xb, xa); np.testing.assert_array_equal(rb, ra)
-    mask = (np.arange(200) % 3 == 0).astype(np.uint8)
-    for k in range(5):
-        b.step_direct_dev(tape[k].data_ptr(), *(t.data_ptr() for t in ob))
-        a.step_dev(tape[k].data_ptr(), *(t.data_ptr() for t in oa))
-    np.testing.assert_array_equal(b.reset(mask), a.reset(mask))
-    rs_a, rs_b = torch.zeros(200, device=dev, dtype=torch.float64), torch.zeros(200, device=dev, dtype=torch.float64)
-    b.step_direct_dev(tape[7].data_ptr(), *(t.data_ptr() for t in ob))
-    a.step_dev(tape[7].data_ptr(), *(t.data_ptr() for t in oa))
-    a.step_many_dev(16, tape.data_ptr(), oa[0].data_ptr(), rs_a.data_ptr())
-    b.step_many_dev(16, tape.data_ptr(), ob[0].data_ptr(), rs_b.data_ptr())
-    b.step_direct_dev(tape[9].data_ptr(), *(t.data_ptr() for t in ob))
-    a.step_dev(tape[9].data_ptr(), *(t.data_ptr() for t in oa))
-    a.run_tape_dev(30, tape.data_ptr(), 40, *(t.data_ptr() for t in oa), use_graph=_capi.LAUNCH_GRAPH)
-    b.run_tape_dev(30, tape.data_ptr(), 40, *(t.data_ptr() for t in ob), use_graph=_capi.LAUNCH_DIRECT)
-    for f in STATE:
-        np.testing.assert_array_equal(b.get(f), a.get(f), err_msg=f)
-    assert torch.equal(ob[0], oa[0]) and torch.equal(rs_b, rs_a)
-    b.check_errors()
-    a.close(); b.close()
+def test_rainflow_cycle_and_stack_getters_count_what_a_plain_rainflow_counts():
+    """FLEET_F_RF_CYCLES / FLEET_F_RF_STACK (bench.py's workload invariants: the share of EV-steps that push a reversal point / close a
+    cycle) against a plain three-point rainflow over the logged SOC samples of every EV, inside one episode."""
+    g, (b,), rng = _batch(E=6)
+    obs = b.reset()
+    series = [b.get("soc_deg").copy()]
+    ep0 = b.get("episodes").copy()
+    for k in range(150):
+        b.step(rng.uniform(-1, 1, size=(6, g.N)).astype(np.float32))
+        series.append(b.get("soc_deg").copy())
+    assert np.array_equal(b.get("episodes"), ep0)  # still the first episode
+    s = np.stack(series)  # [steps + 1, E, N]
+    want_c, want_s = np.zeros((6, g.N), np.int32), np.zeros((6, g.N), np.int32)
+    for e in range(6):
+        for c in range(g.N):
+            stack, nc, sgn, prev = [s[0, e, c]], 0, 0, s[0, e, c]
+            for x in s[1:, e, c]:
+                if x == prev:
+                    continue
+                sg = 1 if x > prev else 2
+                if sgn and sg != sgn:  # `prev` was a reversal point
+                    stack.append(prev)
+                    while len(stack) >= 3 and not abs(stack[-1] - stack[-2]) < abs(stack[-2] - stack[-3]):
+                        nc += 1
+                        if len(stack) == 3:
+                            stack.pop(0)
+                        else:
+                            last = stack.pop(); stack.pop(); stack.pop(); stack.append(last)
+                sgn, prev = sg, x
+            want_c[e, c], want_s[e, c] = nc, len(stack)
+    np.testing.assert_array_equal(b.get("rf_cycles"), want_c)
+    np.testing.assert_array_equal(b.get("rf_stack"), want_s)
+    assert want_c.sum() > 20 and want_s.max() > 3
+    b.close()

@@ -6,7 +6,7 @@ TAG=${1:-ab}; ROUNDS=${2:-1}; shift; shift
 mkdir -p gpurun_out/r06
 cp fleetrl_amd/libfleet_hip.so /tmp/keep6.so; cp fleetrl_amd/libfleet_hip.gfx950.hsaco /tmp/keep6.hsaco
 trap "cp /tmp/keep6.so fleetrl_amd/libfleet_hip.so; cp /tmp/keep6.hsaco fleetrl_amd/libfleet_hip.gfx950.hsaco" EXIT
-run() { FLEET_BENCH_NO_ERRCHECK=${NOERR:-0} timeout 300 python3 bench.py --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline --no-host-path $2 2>/tmp/r06_err.log | tail -1 | python3 -c "
+run() { FLEET_BENCH_NO_ERRCHECK=${NOERR:-0} timeout 90 python3 bench.py --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline --no-host-path $2 2>/tmp/r06_err.log | tail -1 | python3 -c "
 import sys,json
 try:
     d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']
