@@ -428,33 +428,39 @@ def main():
                 other_paths[name] = {"kernel_ms": kernel_ms(mode), "what": what}
             except Exception as ex:  # (no queue to be had: see launch_note)
                 other_paths[name] = {"kernel_ms": None, "what": f"unavailable: {ex}"}
-    # ---- what the run did: the workload's invariants over a window of W launches (envs that end an episode inside it left out) --
-    W_inv = 16
-    try:
-        inv_before = [(g.batch.get("episodes"), g.batch.get("rf_cycles"), g.batch.get("rf_stack")) for g in groups]
-        run(W_inv)
-        sync()
-        pushes = closures = evsteps = 0
-        for g, (e0, c0, s0) in zip(groups, inv_before):
-            keep = g.batch.get("episodes") == e0
-            dc = (g.batch.get("rf_cycles").astype(np.int64) - c0)[keep].sum()
-            ds = (g.batch.get("rf_stack").astype(np.int64) - s0)[keep].sum()
-            closures += int(dc)
-            pushes += int(ds + 2 * dc)  # a push adds a point, a full cycle removes two (a half cycle one: an upper bound, exact without them)
-            evsteps += int(keep.sum()) * g.N * W_inv
-        invariants = {"push_fraction": pushes / max(evsteps, 1), "closure_fraction": closures / max(evsteps, 1), "window_steps": W_inv,
-                      "ev_steps": evsteps, "what": "share of the EV-steps that push a rainflow reversal point / close a rainflow cycle"}
-    except Exception as ex:  # (an older library run beside the tree by the A/B scripts: no such fields)
-        invariants = {"push_fraction": None, "closure_fraction": None, "what": f"unavailable: {ex}"}
-    # ---- the same launches in the OTHER episode phase (kernel time only) ------------------------------------------------------------
+    # ---- what the run did: the workload's invariants, and the same launches in the OTHER episode phase ---------------------------
+    # The invariants are taken in the STAGGERED state (the stationary mixture of episode ages: the same whatever the shape, the step
+    # count and the prime time of the run were), over a window of W launches, envs that end an episode inside it left out.
+    def workload_invariants(W=16):
+        try:
+            before = [(g.batch.get("episodes"), g.batch.get("rf_cycles"), g.batch.get("rf_stack")) for g in groups]
+            run(W)
+            sync()
+            pushes = closures = evsteps = 0
+            for g, (e0, c0, s0) in zip(groups, before):
+                keep = g.batch.get("episodes") == e0
+                dc = (g.batch.get("rf_cycles").astype(np.int64) - c0)[keep].sum()
+                ds = (g.batch.get("rf_stack").astype(np.int64) - s0)[keep].sum()
+                closures += int(dc)
+                pushes += int(ds + 2 * dc)  # a push adds a point, a full cycle removes two (a half cycle one: an upper bound, exact without them)
+                evsteps += int(keep.sum()) * g.N * W
+            return {"push_fraction": pushes / max(evsteps, 1), "closure_fraction": closures / max(evsteps, 1), "window_steps": W,
+                    "ev_steps": evsteps, "episode_phase": "staggered",
+                    "what": "share of the EV-steps that push a rainflow reversal point / close a rainflow cycle"}
+        except Exception as ex:  # (an older library run beside the tree by the A/B scripts: no such fields)
+            return {"push_fraction": None, "closure_fraction": None, "what": f"unavailable: {ex}"}
+
     if args.phase == "locked":
         stagger()
-        run(args.warmup)
+        run(args.warmup + 32)
+        sync()
+        invariants = workload_invariants()
     else:
+        invariants = workload_invariants()
         for g in groups:
             g.batch.reset_dev(g.obs.data_ptr())
         run(args.warmup + 7)
-    sync()
+        sync()
     other_phase_ms = kernel_ms(use_graph)
     w = torch.tensor(walls, device=cdev, dtype=torch.float64)
     if launched:

@@ -256,7 +256,8 @@ struct FleetStepLaunch {
   unsigned actions_offset[2];
   unsigned packed_n_offset;  // where `p_N` sits: EVs per env | first workgroup of the grid << 16 (a run split over two queues)
   unsigned guard_offset;     // where the eight bytes of the placement record sit (zeros = no check: every launch through HIP)
-  alignas(8) unsigned char args[512];
+  unsigned rec_offset;       // where {blocks pointer, rows, rotate} of a run's FIRST launch sit (the launch that writes the record)
+  alignas(8) unsigned char args[640];  // (also the distance between two argument blocks of a run: fleet_direct.hip, the step kernel's record)
 };
 hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_dtype, float* obs, double* reward, uint8_t* done,
                                float* terminal_obs, FleetStepLaunch* out);

@@ -20,9 +20,10 @@
 //     launches) unless the map workgroup -> die is periodic in 8 and identical from launch to launch;
 //   * the die a queue starts dealing from is NOT a constant of the queue: it moves by one whenever a queue is created or destroyed in
 //     the process (found by this library's own tests: the second queue of a split run moved the first one's; then measured,
-//     tools/ubench/xcc_map.cpp).  So every RUN -- a chain of launches that ends with the release -- starts with a tiny launch that
-//     writes the dies of workgroups 0..7 of that queue, as they are then, into the argument blocks of the run's launches
-//     (fleet_guard_record_kernel), and every step launch compares the die it finds itself on with its slot of that record
+//     tools/ubench/xcc_map.cpp).  So the FIRST launch of every run -- a chain of launches that ends with the release; its first
+//     launch reads what the previous release made everybody's and may sit anywhere -- writes the dies of its first eight workgroups,
+//     as they are then, into the argument blocks of the run's other launches, and every other launch compares the die it finds
+//     itself on with its slot of that record
 //     (fleet_kernels.hip, "Placement guard": one scalar load from the argument segment and one s_getreg at the end of the step): a
 //     launch that lands elsewhere raises FLEET_DEVERR_PLACEMENT, which fleet_check_errors / the host step report as a hard error.
 //     A run whose queue moved in its middle is void and says so; between runs a move is harmless;
@@ -124,7 +125,6 @@ struct FleetDirect {
   std::map<std::string, KernelObject> kernels;
   // placement (see the header comment)
   KernelObject probe_kernel;       // fleet_probe_xcc_kernel: the open-time probe
-  KernelObject record_kernel;      // fleet_guard_record_kernel: first launch of every run
   uint32_t* probe_out = nullptr;   // device: kProbeLaunches x kProbeMaxGrid words
   char* probe_kargs = nullptr;     // device: one 64-byte argument block per probe launch
   uint32_t guard[2] = {0, 0};      // what the probe found per queue (bit 31 + eight 3-bit dies): information, see fleet_direct_probed
@@ -137,13 +137,13 @@ struct FleetDirect {
   unsigned block = 0;
   int parts = 1;              // 1: the whole grid on queue 0; 2: the grid as two ranges of workgroups, one per queue
   unsigned part_grid[2] = {0, 0};
-  char* kargs_dev = nullptr;  // parts x tape_len blocks of kBlockBytes (part-major), then per part the 64-byte argument block of its
-                              // record launch
+  char* kargs_dev = nullptr;  // parts x tape_len blocks of kBlockBytes (part-major), then per part the block of the run's FIRST launch
+                              // (tape row 0's with the recording arguments: it writes the placement record into the others)
   size_t kargs_cap = 0;
   int tape_len = 0;
   std::vector<unsigned char> kargs_host;  // what was uploaded (the fault hook patches a block of it)
-  unsigned packed_n_offset = 0, guard_offset = 0;
-  static constexpr size_t kBlockBytes = 512;
+  unsigned packed_n_offset = 0, guard_offset = 0, rec_offset = 0;
+  static constexpr size_t kBlockBytes = sizeof(FleetStepLaunch::args);
   // signals: a pool; the ones handed out since the last wait; per timed run what its spans are read from
   std::vector<hsa_signal_t> pool, pending;
   struct Mark { hsa_signal_t first[2], last[2]; int parts; std::vector<hsa_signal_t> each; };
@@ -390,7 +390,6 @@ int fleet_direct_open(int hip_device, FleetDirect** out, std::string* err) {
   }
   int rc = kernel_by_name(q, "fleet_probe_xcc_kernel", &q->probe_kernel, err);
   if (rc != FLEET_OK) return fail(rc);
-  if ((rc = kernel_by_name(q, "fleet_guard_record_kernel", &q->record_kernel, err)) != FLEET_OK) return fail(rc);
   if ((rc = probe_queue(q, 0, err)) != FLEET_OK) return fail(rc);
 #ifdef FLEET_STAMPS
   g_last_direct = q;
@@ -497,7 +496,7 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
         return FLEET_ERR_UNSUPPORTED;
       }
   const size_t blocks_bytes = (size_t)parts * tape_len * FleetDirect::kBlockBytes;
-  const size_t need = blocks_bytes + (size_t)parts * 64;
+  const size_t need = blocks_bytes + (size_t)parts * FleetDirect::kBlockBytes;
   std::vector<unsigned char> host(need, 0);
   for (int part = 0; part < parts; ++part)
     for (int k = 0; k < tape_len; ++k) {
@@ -512,7 +511,8 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
         packed = (int32_t)(((uint32_t)packed & 0xffffu) | (part_grid[0] << 16));
         memcpy(b + L.packed_n_offset, &packed, 4);
       }
-      memset(b + L.guard_offset, 0, 8);  // the placement record: written by the run's first launch (fleet_direct_submit)
+      memset(b + L.guard_offset, 0, 8);  // the placement record: written by the run's first launch
+      memset(b + L.rec_offset, 0, 16);
     }
   char* dev = q->kargs_dev;
   if (need > q->kargs_cap) {
@@ -522,10 +522,12 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
       return FLEET_ERR_HIP;
     }
   }
-  for (int part = 0; part < parts; ++part) {  // the record launch of each part: (its blocks, rows, stride, offset of the record, rotate)
-    struct { char* blocks; int rows; unsigned stride, offset; int rotate; } ra = {dev + (size_t)part * tape_len * FleetDirect::kBlockBytes, tape_len,
-                                                                                   (unsigned)FleetDirect::kBlockBytes, L.guard_offset, 0};
-    memcpy(host.data() + blocks_bytes + (size_t)part * 64, &ra, sizeof ra);
+  for (int part = 0; part < parts; ++part) {  // the first launch of a run: tape row 0's block + where the part's other blocks are
+    unsigned char* f = host.data() + blocks_bytes + (size_t)part * FleetDirect::kBlockBytes;
+    memcpy(f, host.data() + (size_t)part * tape_len * FleetDirect::kBlockBytes, FleetDirect::kBlockBytes);
+    struct { char* blocks; int rows, rotate; } ra = {dev + (size_t)part * tape_len * FleetDirect::kBlockBytes, tape_len, 0};
+    static_assert(sizeof ra == 16, "the recording arguments");
+    memcpy(f + L.rec_offset, &ra, sizeof ra);
   }
   if (hipMemcpy(dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) {
     if (dev != q->kargs_dev) (void)hipFree(dev);
@@ -547,6 +549,7 @@ int fleet_direct_prepare(FleetDirect* q, const FleetStepLaunch& L, const void* t
   q->tape_len = tape_len;
   q->packed_n_offset = L.packed_n_offset;
   q->guard_offset = L.guard_offset;
+  q->rec_offset = L.rec_offset;
   return FLEET_OK;
 }
 
@@ -608,15 +611,13 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, std::string* err) 
         m.each[(size_t)i * q->parts + part] = s;
       }
   }
-  // the run's placement record (header comment): the dies of workgroups 0..7 of each queue, as they are now, into the argument blocks
-  const size_t rec_args = (size_t)q->parts * q->tape_len * FleetDirect::kBlockBytes;
-  for (int part = 0; part < q->parts; ++part) {
-    if (q->fault_rotate) {  // test hook: a record shifted by one workgroup
-      const int one = 1;
-      if (hipMemcpy(q->kargs_dev + rec_args + (size_t)part * 64 + 20, &one, 4, hipMemcpyHostToDevice) != hipSuccess) return FLEET_ERR_HIP;
-    }
-    write_packet(q->queue[part], q->record_kernel, 64, 8, q->kargs_dev + rec_args + (size_t)part * 64, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE,
-                 hsa_signal_t{});
+  // the run's first launch goes out with the block that has it write the placement record into the others (header comment)
+  const size_t first_blocks = (size_t)q->parts * q->tape_len * FleetDirect::kBlockBytes;
+  if (q->fault_rotate) {  // test hook: a record shifted by one workgroup
+    const int one = 1;
+    for (int part = 0; part < q->parts; ++part)
+      if (hipMemcpy(q->kargs_dev + first_blocks + (size_t)part * FleetDirect::kBlockBytes + q->rec_offset + 12, &one, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return FLEET_ERR_HIP;
   }
   for (int i = 0; i < steps; ++i)
     for (int part = 0; part < q->parts; ++part) {  // step by step, queue by queue: both chains get going at once
@@ -629,7 +630,9 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, std::string* err) 
       const int acq = (i == 0) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
       const int rel = (i == steps - 1) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE;
       write_packet(q->queue[part], q->kernel, q->block, q->part_grid[part],
-                   q->kargs_dev + ((size_t)part * q->tape_len + (size_t)(i % q->tape_len)) * FleetDirect::kBlockBytes, acq, rel, sig);
+                   i == 0 ? q->kargs_dev + first_blocks + (size_t)part * FleetDirect::kBlockBytes
+                          : q->kargs_dev + ((size_t)part * q->tape_len + (size_t)(i % q->tape_len)) * FleetDirect::kBlockBytes,
+                   acq, rel, sig);
     }
   if (timed) {
     if (timed == 1 && steps == 1)  // (one packet cannot carry two signals: its own start and end are the span then)
@@ -644,7 +647,8 @@ int fleet_direct_submit(FleetDirect* q, int steps, int timed, std::string* err) 
     if (rc != FLEET_OK) return rc;
     const int zero = 0;
     for (int part = 0; part < q->parts; ++part)
-      if (hipMemcpy(q->kargs_dev + rec_args + (size_t)part * 64 + 20, &zero, 4, hipMemcpyHostToDevice) != hipSuccess) return FLEET_ERR_HIP;
+      if (hipMemcpy(q->kargs_dev + first_blocks + (size_t)part * FleetDirect::kBlockBytes + q->rec_offset + 12, &zero, 4, hipMemcpyHostToDevice) != hipSuccess)
+        return FLEET_ERR_HIP;
     return FLEET_OK;
   }
   return FLEET_OK;

@@ -963,8 +963,10 @@ struct StepKernargs {
   uint8_t* done;
   float* terminal_obs;
   int32_t* done_count;
-  unsigned long long guard_bytes;  // placement record of the chain of launches this one belongs to (see the kernel, "Placement
-                                   // guard"): byte k = 0x80 | die of workgroups w with (w & 7) == k; 0 = no check (every launch through HIP)
+  unsigned long long guard_bytes;  // placement record of the run this launch belongs to (see the kernel, "Placement guard"): byte k =
+                                   // 0x80 | die of workgroups w with (w & 7) == k; 0 = no check (every launch through HIP)
+  unsigned char* rec_blocks;       // the FIRST launch of a run on the library's own queue: the argument blocks of the run's other launches
+  int rec_rows, rec_rotate;        // (rec_rows blocks, FleetStepLaunch::kBlockBytes apart), into which it writes that record; else nullptr
 };
 static_assert(offsetof(StepKernargs, d_arg) == offsetof(StepKernargPrefix, d_arg) && sizeof(StepKernargs) <= sizeof(FleetStepLaunch::args),
               "the argument block of a described launch");
@@ -987,7 +989,8 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     FleetDev d_arg, const void* __restrict__ actions, int act_mode, int K,
                                                                float* __restrict__ obs, double* __restrict__ reward,
                                                                uint8_t* __restrict__ done, float* __restrict__ terminal_obs,
-                                                               int32_t* __restrict__ done_count, unsigned long long guard_bytes) {
+                                                               int32_t* __restrict__ done_count, unsigned long long guard_bytes,
+                                                               unsigned char* __restrict__ rec_blocks, int rec_rows, int rec_rotate) {
   FLEET_STAMP_RT(9);
   FLEET_STAMP(0);
   // The argument block is ~150 dwords of scalars for ~100 scalar registers.  One step per launch, one EV per lane: what the END
@@ -1482,26 +1485,38 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     }
   }
   // Placement guard (single-step launches on the library's own queue, fleet_direct.hip).  Such launches carry no release fence,
-  // which is only correct while workgroup w of every launch of a chain runs on the die (XCC) that ran workgroup w of the previous
+  // which is only correct while workgroup w of every launch of a run runs on the die (XCC) that ran workgroup w of the previous
   // one -- a die's L2 is the only place the env's newest state lives.  The hardware deals the workgroups of a dispatch to the dies
   // round-robin from a die that belongs to the QUEUE, but that die is not a constant: it moves by one whenever a queue is created
   // or destroyed in the process (measured: tools/ubench/xcc_map.cpp) and the platform promises nothing (MI355X_MICROARCH.md,
-  // "Workgroup dispatch, XCD placement").  So every chain starts with a tiny launch that writes the dies of workgroups 0..7 of
-  // THIS queue, as they are then, into the argument blocks of the chain's launches (`fleet_guard_record_kernel`), and every step
-  // launch compares the die it finds itself on with its slot of that record -- here, at the very end, from the kernel-argument
-  // segment itself: one scalar load that hits the constant cache, one s_getreg, a few scalar instructions, nothing held across
-  // the step (a record carried from the entry cost 1-3 % per launch in spilled scalars, one fetched by a device-scope vector load
-  // 4 %: profiles/r06_experiments/placement_guard_cost.log).  A mismatch raises FLEET_DEVERR_PLACEMENT (sticky; the chain's
-  // results are void, fleet_check_errors tells the caller).  Launches through HIP carry a record of zeros: no check.
+  // "Workgroup dispatch, XCD placement").  So the FIRST launch of every run -- which reads state that the previous run's release
+  // made everybody's, and may therefore sit anywhere -- writes the dies of its first eight workgroups into the argument blocks of
+  // the run's other launches (byte k of `guard_bytes` there = 0x80 | die of workgroup k; written through and drained), and every
+  // other launch compares the die it finds itself on with its slot of that record -- here, at the very end, from the
+  // kernel-argument segment itself: one scalar load that hits the constant cache, one s_getreg, a few scalar instructions, nothing
+  // held across the step (a record carried from the entry cost 1-3 % per launch in spilled scalars, one fetched by a device-scope
+  // vector load 4 %: profiles/r06_experiments/placement_guard_cost.log).  A mismatch raises FLEET_DEVERR_PLACEMENT (sticky; the
+  // run's results are void, fleet_check_errors tells the caller).  Launches through HIP carry a record of zeros: no check.
   if constexpr (!MULTI) {
+    struct Tail { unsigned long long rec; unsigned char* blocks; int rows, rotate; };
+    static_assert(offsetof(StepKernargs, rec_blocks) == offsetof(StepKernargs, guard_bytes) + 8, "one 24-byte piece of the argument block");
     typedef const __attribute__((address_space(4))) char* karg_ptr;
     karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StepKernargs, guard_bytes);
     asm volatile("" : "+s"(kp));  // (not hoisted to the entry: see late_args)
-    const unsigned long long rec = *(const __attribute__((address_space(4))) unsigned long long*)kp;
-    const unsigned slot = (unsigned)(rec >> (8u * ((blockIdx.x + (unsigned)wg_base) & 7u))) & 0xffu;
+    const Tail& tl = *(const Tail*)(const __attribute__((address_space(4))) Tail*)kp;
+    const unsigned w = blockIdx.x + (unsigned)wg_base;
     const unsigned have = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, bits [3:0]
+    const unsigned slot = (unsigned)(tl.rec >> (8u * (w & 7u))) & 0xffu;
     if ((slot & 0x80u) && (slot & 0xfu) != have) err |= FLEET_DEVERR_PLACEMENT;
-    (void)guard_bytes;
+    if (tl.blocks != nullptr && blockIdx.x < 8 && threadIdx.x < 64) {  // the run's first launch: its first eight workgroups record
+      // (the blocks are FleetStepLaunch::kBlockBytes apart; `rotate`: 0 -- or, test hook of the guard's negative test, the record
+      // shifted by that many workgroups)
+      unsigned char* at = tl.blocks + offsetof(StepKernargs, guard_bytes) + ((w + (unsigned)tl.rotate) & 7u);
+      for (int r = (int)threadIdx.x; r < tl.rows; r += 64)
+        __hip_atomic_store(at + (size_t)r * sizeof(FleetStepLaunch::args), (unsigned char)(0x80u | have), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    (void)guard_bytes; (void)rec_blocks; (void)rec_rows; (void)rec_rotate;
   }
   if (err && env_ok) {  // FLEET_DEVERR_*: per env, and OR-ed into the one word the host-pointer step brings back with its results
     atomicOr(&d.env[e].err, err);
@@ -1686,7 +1701,7 @@ void launch_many(const FleetDev& d, dim3 grid, dim3 block, const void* actions, 
 #define FLEET_PRE_ARGS d.hot, d.run, d.soh, actions, d.E, d.N, d.env,  /* the leading arguments (12 dwords, preloaded) */
 #define FLEET_MANY(MODE)                                                                                                          \
   hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, WIDE, false, false, MODE>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, act_mode, K, \
-                     obs, reward, done, terminal_obs, done_count, 0ull)
+                     obs, reward, done, terminal_obs, done_count, 0ull, nullptr, 0, 0)
   if (G < 32) FLEET_MANY(kModeAll);
   else if (d.real_time) FLEET_MANY((G < 32 ? kModeAll : kModeRt));
   else if (act_mode >= FLEET_ACT_POLICY_UNCONTROLLED) FLEET_MANY((G < 32 ? kModeAll : kModePolicy));
@@ -1706,12 +1721,15 @@ inline void describe_launch(FleetStepLaunch* L, const void* host_fn, dim3 grid, 
   L->actions_offset[0] = (unsigned)offsetof(StepKernargs, p_actions); L->actions_offset[1] = (unsigned)offsetof(StepKernargs, actions);
   L->packed_n_offset = (unsigned)offsetof(StepKernargs, p_N);
   L->guard_offset = (unsigned)offsetof(StepKernargs, guard_bytes);
+  L->rec_offset = (unsigned)offsetof(StepKernargs, rec_blocks);  // (then rec_rows and rec_rotate)
+  static_assert(offsetof(StepKernargs, rec_rows) == offsetof(StepKernargs, rec_blocks) + 8 && offsetof(StepKernargs, rec_rotate) == offsetof(StepKernargs, rec_rows) + 4,
+                "fleet_direct_prepare fills the three as one 16-byte piece");
   memcpy(L->args, &a, sizeof a);
 }
 #define FLEET_LAUNCH_SINGLE(KERNEL, GRID)                                                                                              \
   do {                                                                                                                                 \
     if (t_describe) describe_launch(t_describe, (const void*)(KERNEL), GRID, block, d, actions, f64, obs, reward, done, terminal_obs, done_count); \
-    else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done, terminal_obs, done_count, 0ull); \
+    else hipLaunchKernelGGL(KERNEL, GRID, block, 0, s, FLEET_PRE_ARGS d, actions, f64, 1, obs, reward, done, terminal_obs, done_count, 0ull, nullptr, 0, 0); \
   } while (0)
 
 template <int G, int DEG>
@@ -1752,7 +1770,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, (G == 64)>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, (G == 64), true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward,
-                         done, terminal_obs, done_count, 0ull);
+                         done, terminal_obs, done_count, 0ull, nullptr, 0, 0);
     else
       launch_many<G, DEG, (G == 64)>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   } else {
@@ -1762,7 +1780,7 @@ hipError_t launch_step_gd(const FleetDev& d, const void* actions, int act_dtype,
       FLEET_LAUNCH_SINGLE((fleet_step_kernel<G, DEG, false, false>), grid);
     else if (d.log_pos)
       hipLaunchKernelGGL((fleet_step_kernel<G, DEG, true, false, true>), grid, block, 0, s, FLEET_PRE_ARGS d, actions, f64, K, obs, reward, done,
-                         terminal_obs, done_count, 0ull);
+                         terminal_obs, done_count, 0ull, nullptr, 0, 0);
     else
       launch_many<G, DEG, false>(d, grid, block, actions, f64, K, obs, reward, done, terminal_obs, done_count, s);
   }
@@ -1792,21 +1810,6 @@ hipError_t launch_reset_g(const FleetDev& d, const uint8_t* mask, float* obs, hi
 // (HW_REG_XCC_ID, all bits).  A symbol with C linkage: resolved by name in the code object the HSA loader holds.
 extern "C" __global__ void fleet_probe_xcc_kernel(uint32_t* __restrict__ out) {
   if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-}
-// The first launch of every chain on the library's own queue (eight workgroups): workgroup k writes 0x80 | (the die it runs on) into
-// byte k of the placement record of every argument block of the chain's step launches (`blocks`: `rows` blocks, `stride` bytes apart,
-// the record `offset` bytes into each; fleet_step_kernel's argument `guard_bytes`).  Written through and drained, so that the step
-// launches behind it -- whose constant caches are invalidated when they start -- read it from memory.
-// (`rotate`: 0 -- or, test hook of the guard's negative test, the record shifted by that many workgroups.)
-extern "C" __global__ void fleet_guard_record_kernel(unsigned char* __restrict__ blocks, int rows, unsigned stride, unsigned offset, int rotate) {
-  if (blockIdx.x >= 8) return;
-  const unsigned char v = (unsigned char)(0x80u | (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xfu));
-  const unsigned slot = (blockIdx.x + (unsigned)rotate) & 7u;
-  // (64 = the workgroup size the library launches it with: a kernel whose packets are written by hand must not read blockDim / gridDim --
-  // they live in the implicit arguments HIP appends to the argument block, which these launches do not carry)
-  for (int r = (int)threadIdx.x; r < rows; r += 64)
-    __hip_atomic_store(blocks + (size_t)r * stride + offset + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // Which sources this code was compiled from (fleetrl_amd/build.py passes the hash of the sources and flags to BOTH artefacts):
 // fleet_direct_open reads the code object's copy through the HSA loader and refuses a code object that is not the library's twin.
