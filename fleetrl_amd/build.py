@@ -16,8 +16,12 @@ HEADERS = ("fleet_device.h", "fleet_direct.h", os.path.join("..", "..", "include
 # (185 -> 124 VGPRs, +31 % env-steps/s measured) and does nothing for the loop-free single-step kernel.
 # -mllvm -amdgpu-kernarg-preload-count=12: the step kernel's first twelve argument dwords (env record / state record /
 # action pointers, E, N) arrive in scalar registers with the wave instead of through an argument fetch (-2.5 % per step).
+# -mllvm -amdgpu-sched-strategy=max-memory-clause: the machine scheduler groups the loads of a burst into clauses instead of
+# interleaving them with arithmetic (round 6: -0.7 % per launch at 4096 x 50, -1 % at 2048 x 50, +3 % on the K-step entry, +-0 on the
+# large shapes; max-ilp, wave-priority insertion, early if-conversion, no post-RA scheduler, 16 preloaded dwords: all equal or worse,
+# profiles/r06_experiments/compiler_scheduling_flags.log).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
-         "-mllvm", "-amdgpu-kernarg-preload-count=12", "-shared"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=12", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause", "-shared"]
 
 
 # the library also talks to the HSA runtime directly (fleet_direct.hip: AQL packets of its own for runs of steps)

@@ -1,5 +1,5 @@
 # usage (build container): bash tools/kres.sh [extra hipcc flags] -- registers / scratch / occupancy of every step-kernel instance
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12 "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12 -mllvm -amdgpu-sched-strategy=max-memory-clause "$@" \
   -c "$(dirname "$0")/../fleetrl_amd/csrc/fleet_kernels.hip" -o /tmp/kres.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import re,sys
 cur=None

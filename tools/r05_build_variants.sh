@@ -2,7 +2,7 @@
 # Cross-compiles one libfleet_hip.so per entry into ab_variants/ (git-ignored, travels with gpurun); a git revision is exported to
 # a temporary directory first, so that the round-4 kernel can run beside the tree's on the same box (tools/r05_ab.sh).
 cd "$(dirname "$0")/.." && mkdir -p ab_variants && rm -f ab_variants/*.so ab_variants/*.hsaco
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -mllvm -amdgpu-kernarg-preload-count=12 -mllvm -amdgpu-sched-strategy=max-memory-clause"
 for spec in "$@"; do
   tag="${spec%%=*}"; rest="${spec#*=}"; src="${rest%%|*}"; flags="${rest#*|}"; [ "$flags" = "$rest" ] && flags=""
   if [ "$src" = "." ]; then dir=.; else dir=$(mktemp -d /tmp/r05src.XXXX); git archive "$src" fleetrl_amd/csrc include | tar -x -C "$dir"; sed -i "s/#define FLEET_ABI_VERSION .*/$(grep '#define FLEET_ABI_VERSION' include/fleet_hip.h)/" "$dir/include/fleet_hip.h"; fi  # (an older revision answers to the tree's ABI number: the public structures have not changed since version 4)
