@@ -237,6 +237,9 @@ def main():
                          "de-phased first (masked resets spread over one episode length), so that every launch sees the stationary mixture "
                          "of episode ages and ends a few episodes.  Whichever is timed, the other's kernel time is reported beside it "
                          "(roofline.other_phase)")
+    ap.add_argument("--lean", action="store_true",
+                    help="only the headline's launches (profiling runs: rocprofv3 aggregates by kernel name, and the other launch path, the "
+                         "other episode phase, the K-step entry and the host path all run instances of the same kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--tape-len", type=int, default=32,
@@ -417,12 +420,12 @@ def main():
     # path, then through the other paths of the same kernel on the same state (reported beside it, never as `value`)
     ev_regions = kernel_regions(use_graph)
     other_paths = {}
-    for name, mode, what in (
+    for name, mode, what in (() if args.lean else (
             ("open_loop_direct_queue", 2, "OPEN LOOP: the library's own queue, no L2 write-back between the launches of a region; a step's "
                                           "outputs are visible after the region only (FLEET_LAUNCH_DIRECT: a recorded tape, an open-loop rollout)"),
             ("closed_loop_hip_graph" if args.steps >= graph_len else "closed_loop_hip_eager", 1 if args.steps >= graph_len else 0,
              "CLOSED LOOP: HIP's launches, an agent-scope release (L2 write-back) at every kernel boundary -- every step's outputs are "
-             "visible before the next step starts: what fleet_step_dev and every Gym / SB3 loop get")):
+             "visible before the next step starts: what fleet_step_dev and every Gym / SB3 loop get"))):
         if (mode >= 2) != (use_graph >= 2):
             try:
                 other_paths[name] = {"kernel_ms": kernel_ms(mode), "what": what}
@@ -450,18 +453,21 @@ def main():
         except Exception as ex:  # (an older library run beside the tree by the A/B scripts: no such fields)
             return {"push_fraction": None, "closure_fraction": None, "what": f"unavailable: {ex}"}
 
-    if args.phase == "locked":
+    if args.lean:
+        invariants, other_phase_ms = {"push_fraction": None, "closure_fraction": None, "what": "not taken (--lean)"}, None
+    elif args.phase == "locked":
         stagger()
         run(args.warmup + 32)
         sync()
         invariants = workload_invariants()
+        other_phase_ms = kernel_ms(use_graph)
     else:
         invariants = workload_invariants()
         for g in groups:
             g.batch.reset_dev(g.obs.data_ptr())
         run(args.warmup + 7)
         sync()
-    other_phase_ms = kernel_ms(use_graph)
+        other_phase_ms = kernel_ms(use_graph)
     w = torch.tensor(walls, device=cdev, dtype=torch.float64)
     if launched:
         dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
@@ -546,7 +552,8 @@ def main():
         bytes_launch = sum(g.bytes_step * g.E for g in groups)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         g0 = max(groups, key=lambda g: g.E * g.N)
-        per = g0.batch.time_steps_dev(min(args.steps, 512), g0.tape.data_ptr(), g0.L, g0.obs.data_ptr(), g0.reward.data_ptr(), g0.done.data_ptr())
+        per = [float("nan")] if args.lean else g0.batch.time_steps_dev(min(args.steps, 512), g0.tape.data_ptr(), g0.L, g0.obs.data_ptr(),
+                                                                        g0.reward.data_ptr(), g0.done.data_ptr())
         # K-steps-per-launch entry (open-loop rollouts), reported aside
         # (an open-loop rollout of K steps consumes K steps of actions: a tape of its own where the single-step tape is shorter)
         K = min(64, max(args.steps, 1))
@@ -634,7 +641,8 @@ def main():
                                  "bytes against the HBM peak, not measured HBM traffic (`traffic`: rocprofv3 counters)",
                          # the same kernel on the same state through the other launch paths (kernel time only; never `value`)
                          "other_launch_paths": paths,
-                         "other_phase": dict(path_line(other_phase_ms), phase="staggered" if args.phase == "locked" else "locked")},
+                         "other_phase": (dict(path_line(other_phase_ms), phase="staggered" if args.phase == "locked" else "locked")
+                                         if other_phase_ms else None)},
             # K steps per launch: only the last step's observation is part of the result (and written), so the
             # algorithmic bytes per env-step are smaller by the observation row for K-1 of the K steps
             "step_many": {"K": K, "group": g0.use_case, "env_steps_per_s": g0.E * K * many_reps / (many_ms * 1e-3),

@@ -1,4 +1,4 @@
-# usage: bash tools/prof_traffic.sh <tag> [bench args...]   (on the GPU box through gpurun); tag = r05_traffic_<config>, the
+# usage: bash tools/prof_traffic.sh <tag> [bench args...]   (on the GPU box through gpurun); tag = r06_traffic_<config>, the
 # result (gpurun_out/prof/<tag>/traffic.json) is what gets committed as profiles/<tag>.json
 # HBM traffic of the step kernel from the L2's memory-side counters, collected as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), kernel-trace only.
@@ -8,9 +8,9 @@ TAG=$1; shift
 OUT=$R/gpurun_out/prof/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > $OUT/bench_write.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > $OUT/bench_l2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --lean "$@" > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --lean "$@" > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --lean "$@" > $OUT/bench_l2.log 2>&1
 python3 - "$OUT" "$@" <<'PY'
 import glob, json, os, sys
 import pandas as pd

@@ -1,5 +1,5 @@
 # usage (GPU box): [NOERR=1] [STEPS=1000] bash tools/r06_ab.sh <tag> <rounds> "<bench args>" ["<bench args>" ...]
-# Every ab_variants/*.so (tools/r05_build_variants.sh) at every argument set, back to back on this device, `rounds` times
+# Every ab_variants/*.so (tools/build_variants.sh) at every argument set, back to back on this device, `rounds` times
 # (box-to-box variance is larger than most effects).  One line per run: kernel time from the dispatch timestamps / HIP events.
 cd $GRAFT_REPO_ROOT
 TAG=${1:-ab}; ROUNDS=${2:-1}; shift; shift
