@@ -193,10 +193,11 @@ def test_large_batch_runs_on_two_queues_bit_identically():
         b.close()
 
 
-@pytest.mark.parametrize("E,steps,queues", [(4096, 2500, 1), (16384, 700, 2)])
+@pytest.mark.parametrize("E,steps,queues", [(4096, 2500, 1), (16384, 700, 2), (4096, 100000, 1)])
 def test_direct_long_run_at_the_bench_shapes(E, steps, queues):
     """The headline batch (4096 x 50, one queue) over 13 episodes and the 16384 x 50 batch (two queues) over 3: the state the library's
-    own launches leave is the stream launches' state, word for word -- every env, every EV, the rainflow counts and the SoH included."""
+    own launches leave is the stream launches' state, word for word -- every env, every EV, the rainflow counts and the SoH included.
+    The third case is a soak: 100 000 launches in ONE run (520 episodes per env, every launch checked by the placement guard)."""
     from fleetrl_amd.batch import FleetBatch
     from fleetrl_amd.config import resolve_config
     from fleetrl_amd.params import make_params, time_features
