@@ -407,15 +407,23 @@ def main():
     # a short run mostly measures the host's wake-up after the synchronize (tens of microseconds against 20 launches of 9 us), so
     # R regions are run back to back and the MEDIAN one is reported (`reps`, with the fastest and slowest beside it); inside a
     # region the wait for the device is a spin on hipStreamQuery instead of a blocking synchronize.
-    walls = []
+    # N > 1: a rank's span ends when ITS device is idle after the K launches; the closing barrier follows, and the line reports the
+    # MAX over the ranks of those spans (with the closing RCCL barrier inside the span every rank would report the same figure, the
+    # slowest rank's PLUS a collective's latency, and the MAX over ranks would be moot).  `ms_per_step_incl_closing_barrier` keeps the
+    # other reading beside it.  N = 1: the synchronize IS the barrier, one figure.
+    walls, walls_closed = [], []
     for _ in range(reps):
         barrier()
         t0 = time.perf_counter()
         run(args.steps)
         for g in groups:
             g.batch.spin_wait()
-        barrier()
+        torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
+        if launched:
+            dist.barrier()
+            torch.cuda.synchronize()
+        walls_closed.append(time.perf_counter() - t0)
     # the kernels' own time (roofline), kept out of the wall-clock regions (kernel_regions above) -- through the headline's launch
     # path, then through the other paths of the same kernel on the same state (reported beside it, never as `value`)
     ev_regions = kernel_regions(use_graph)
@@ -468,10 +476,10 @@ def main():
         run(args.warmup + 7)
         sync()
         other_phase_ms = kernel_ms(use_graph)
-    w = torch.tensor(walls, device=cdev, dtype=torch.float64)
+    w = torch.tensor([walls, walls_closed], device=cdev, dtype=torch.float64)
     if launched:
         dist.all_reduce(w, op=dist.ReduceOp.MAX)  # every region: the slowest rank's time
-    walls = [float(x) for x in w.cpu()]
+    walls, walls_closed = ([float(x) for x in row] for row in w.cpu())
     order = sorted(range(reps), key=lambda i: walls[i])
     wall = walls[order[reps // 2]]
     ev_ms = sorted(ev_regions, key=max)[len(ev_regions) // 2]
@@ -607,7 +615,9 @@ def main():
             "reps": reps, "ms_per_step_min": min(walls) * 1e3 / args.steps, "ms_per_step_max": max(walls) * 1e3 / args.steps,
             # how `ms_per_step` / `value` were taken (not comparable with rounds 1-2, which timed ONE region with a blocking sync)
             "timing": f"median of {reps} back-to-back regions of exactly {args.steps} launches each, barrier + synchronize on both "
-                      "sides, the wait inside a region spins on hipStreamQuery",
+                      "sides, the wait inside a region spins on hipStreamQuery"
+                      + ("; a rank's span ends when its own device is idle (MAX over ranks), the closing barrier follows" if launched else ""),
+            **({"ms_per_step_incl_closing_barrier": sorted(walls_closed)[reps // 2] * 1e3 / args.steps} if launched else {}),
             "errcheck": check,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -93,6 +93,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["episodes_gathered"] == 2 * 768  # both ranks' finished episodes arrived through the gather
     assert abs(d["value"] - 2 * 768 * 400 / (d["ms_per_step"] * 400 * 1e-3)) / d["value"] < 1e-9  # whole-job aggregate
     assert "cpu_baseline" not in d and "host_path" not in d  # single-GPU-run items
+    # N > 1: a rank's span ends when its own device is idle (MAX over ranks); the reading with the closing barrier inside is beside it
+    assert d["ms_per_step_incl_closing_barrier"] >= d["ms_per_step"] and "closing barrier follows" in d["timing"]
 
 
 def test_bench_plain_python_starts_its_own_ranks():
@@ -119,6 +121,7 @@ def test_bench_rccl_branch_with_one_rank():
     assert res.returncode == 0, res.stderr[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["episodes_gathered"] == 512
+    assert d["ms_per_step_incl_closing_barrier"] >= d["ms_per_step"]  # (the closing barrier of a region is an RCCL collective here)
     # ... and the same gather issued by the C ABI itself (one ncclAllGather on the handle's stream, --gather capi)
     res = subprocess.run(cmd + ["--gather", "capi"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
