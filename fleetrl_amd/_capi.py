@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 DEG_NONE, DEG_LINEAR, DEG_RAINFLOW = 0, 1, 2
@@ -48,6 +48,7 @@ FIELDS = {
     "last_ep_len_f64": (20, np.float64, False),
     "rf_cycles": (21, np.int32, True),
     "rf_stack": (22, np.int32, True),
+    "rf_until": (23, np.int32, False),
 }
 
 _I32_FIELDS = (
@@ -194,6 +195,9 @@ def load_library():
     lib.fleet_step_many_dev.argtypes = [vp, C.c_int, vp, C.c_int, f32p, f64p, vp]
     lib.fleet_rollout_policy_dev.argtypes = [vp, C.c_int, C.c_int, f32p, f64p, vp]
     lib.fleet_set_night_policy.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    if hasattr(lib, "fleet_set_rainflow_count_all"):  # (absent from the older libraries the A/B scripts run beside the tree's)
+        lib.fleet_set_rainflow_count_all.argtypes = [vp, C.c_int]
+        lib.fleet_set_rainflow_count_all.restype = C.c_int
     lib.fleet_reset_host.argtypes = [vp, u8p, f32p]
     lib.fleet_step_host.argtypes = [vp, vp, C.c_int, f32p, f64p, u8p, f32p]
     lib.fleet_get.argtypes = [vp, C.c_int, vp]
@@ -256,5 +260,5 @@ EXPORTED_SYMBOLS = (
     "fleet_host_alloc", "fleet_host_free", "fleet_last_step_episodes", "fleet_last_step_error_bits",
     "fleet_time_regions_begin", "fleet_time_regions_read", "fleet_rccl_unique_id", "fleet_rccl_comm_create",
     "fleet_rccl_comm_destroy", "fleet_gather_episode_stats_rccl", "fleet_selftest_division", "fleet_direct_queues", "fleet_selftest_stress",
-    "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault",
+    "fleet_direct_placement", "fleet_direct_split_plan", "fleet_debug_direct_fault", "fleet_set_rainflow_count_all",
 )

@@ -298,6 +298,12 @@ class FleetBatch:
         """Parameters of _capi.POLICY_NIGHT (see fleetrl_amd.policies.night_schedule); clears the per-env window state."""
         self._check(self.lib.fleet_set_night_policy(self.h, int(charging_hour), int(charging_minute), int(max_hours)))
 
+    def set_rainflow_count_all(self, on: bool = True):
+        """Keep the rainflow count running to the end of every episode (from each env's next reset on) instead of stopping it at the
+        episode's last degradation row, after which nobody reads it (include/fleet_hip.h).  Diagnostics / count tests only: state of
+        health, observations and rewards do not depend on it."""
+        self._check(self.lib.fleet_set_rainflow_count_all(self.h, 1 if on else 0))
+
     def run_tape_dev(self, steps: int, tape_ptr: int, tape_len: int, obs_ptr: int, reward_ptr: int, done_ptr: int,
                      use_graph: bool = True, act_dtype: int = _capi.ACT_F32):
         self._check(self.lib.fleet_run_tape_dev(self.h, int(steps), tape_ptr, int(tape_len), act_dtype, obs_ptr,

@@ -203,6 +203,7 @@ const char* validate(const FleetParams* p, const FleetTables* t) {
   if (p->num_envs < 1 || p->num_cars < 1 || p->table_rows < 2) return "num_envs/num_cars/table_rows out of range";
   if (p->num_cars > 65535) return "num_cars: at most 65535 EVs per env";  // (the step kernel's packed argument, fleet_kernels.hip `p_N`)
   if (p->episode_steps < 1 || p->steps_per_hour < 1) return "episode_steps/steps_per_hour out of range";
+  if (p->episode_steps >= FLEET_MAX_EPISODE_STEPS) return "episode_steps exceeds 2^29 - 1 (the env head's sample count is 29 bits wide)";
   if (p->price_lookahead < 0 || p->bl_pv_lookahead < 0) return "negative look-ahead";
   if (p->deg_mode < FLEET_DEG_NONE || p->deg_mode > FLEET_DEG_RAINFLOW) return "unknown deg_mode";
   if (p->deg_mode == FLEET_DEG_RAINFLOW && p->init_soh != 1.0)
@@ -476,6 +477,14 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     if ((rc = dev_upload(b, &d.seg, seg.data(), seg.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_phys, phys.data(), phys.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_flags, flags.data(), flags.size()))) return rc;
+    // the last degradation row at or before every row: where an episode's rainflow count may stop (EnvRec::rf_until)
+    std::vector<int32_t> last_deg((size_t)T);
+    int32_t last = -1;
+    for (int r = 0; r < T; ++r) {
+      if (flags[r] & FLEET_TFLAG_DEG) last = r;
+      last_deg[r] = last;
+    }
+    if ((rc = dev_upload(b, &cd.tab_last_deg, last_deg.data(), last_deg.size()))) return rc;
     if ((rc = dev_upload(b, &d.tab_tail, tail.data(), tail.size()))) return rc;
     HIP_TRY(b, hipStreamSynchronize(b->stream));  // host vectors go out of scope here
   }
@@ -489,6 +498,8 @@ int create_impl(const FleetParams* p, const FleetTables* t, int device, Batch* b
     if ((rc = dev_alloc(b, &cd.night_start, (size_t)E, false))) return rc;
     HIP_TRY(b, hipMemcpyAsync(cd.night_start, idle.data(), idle.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     cd.night_hour = -1; cd.night_minute = 0; cd.night_limit_s = 0;
+    if ((rc = dev_alloc(b, &cd.last_len, (size_t)E))) return rc;  // (zeroed)
+    cd.rf_count_all = 0;
     cd.step_s = (int)std::llround(p->dt * 3600.0);
     HIP_TRY(b, hipStreamSynchronize(b->stream));
   }
@@ -835,6 +846,17 @@ int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minut
   return FLEET_OK;
 }
 
+int fleet_set_rainflow_count_all(fleet_handle h, int on) {
+  FLEET_ENTER(h);
+  if (!h) return FLEET_ERR_INVALID;
+  h->gen += 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->cold_host.rf_count_all = on ? 1 : 0;
+  HIP_TRY(h, hipMemcpy(h->cold_dev, &h->cold_host, sizeof(FleetCold), hipMemcpyHostToDevice));
+  return FLEET_OK;
+}
+
 int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, double* reward_sum, int32_t* done_count) {
   FLEET_ENTER(h);
   if (!h || K < 1 || !obs || !reward_sum ||
@@ -1024,7 +1046,7 @@ static size_t field_bytes(const FleetDev& d, int field) {
     case FLEET_F_LAST_EP_LEN_F64:
     bytes = E * 8; break;
     case FLEET_F_TIME_IDX: case FLEET_F_START_IDX: case FLEET_F_EP_LEN: case FLEET_F_LAST_EP_LEN: case FLEET_F_ERROR_BITS:
-    case FLEET_F_EPISODES: bytes = E * 4; break;
+    case FLEET_F_EPISODES: case FLEET_F_RF_UNTIL: bytes = E * 4; break;
     case FLEET_F_DONE: bytes = E; break;
     default: break;
   }

@@ -112,16 +112,24 @@ static_assert(sizeof(PhysHot) == 64 && sizeof(PhysRow) == 72, "PhysHot is the he
 struct EnvHead {
   int32_t t;         // current table row (episode.time)
   int32_t t_end;     // finish row (episode.finish_time)
-  int32_t nsamp;     // [29:0] len(LogDataDeg.soc_log), [31:30] FLEET_TFLAG_* of row t + 1
+  int32_t nsamp;     // [28:0] len(LogDataDeg.soc_log), [29] the sample the NEXT step logs is still counted (t < EnvRec::rf_until),
+                     // [31:30] FLEET_TFLAG_* of row t + 1
   int32_t episodes;  // finished (or abandoned) episodes: start-schedule index / Philox counter
 };
-#define HEAD_NSAMP(x) ((int32_t)((uint32_t)(x) & 0x3FFFFFFFu))
+#define HEAD_NSAMP(x) ((int32_t)((uint32_t)(x) & 0x1FFFFFFFu))
+#define HEAD_LIVE(x) ((((uint32_t)(x) >> 29) & 1u) != 0u)
 #define HEAD_FLAGS(x) ((uint32_t)(x) >> 30)
-#define HEAD_PACK(nsamp, flags) ((int32_t)(((uint32_t)(nsamp) & 0x3FFFFFFFu) | ((uint32_t)(flags) << 30)))
+#define HEAD_PACK(nsamp, flags, live) \
+  ((int32_t)(((uint32_t)(nsamp) & 0x1FFFFFFFu) | ((live) ? 0x20000000u : 0u) | ((uint32_t)(flags) << 30)))
+#define FLEET_MAX_EPISODE_STEPS 0x1FFFFFFF  // 29-bit sample count
 struct EnvRec {
   EnvHead h;
   int32_t ep_len;          // steps taken in the running episode
-  int32_t last_ep_len;     // length of the last finished episode
+  int32_t rf_until;        // the last row of the running episode on which the degradation model is evaluated (14:45 rows,
+                           // fleet_environment.py:665), -1 if there is none: SOC samples logged AFTER it are never counted -- the
+                           // reference's reset() clears the log (:338-339) before anybody reads them -- so the streaming count
+                           // stops there (a quarter of all EV-steps with 48 h episodes).  INT32_MAX: count everything
+                           // (fleet_set_rainflow_count_all, diagnostics).  Set by reset; head bit 29 caches `t < rf_until`.
   uint32_t err;            // FLEET_DEVERR_* bits
   int32_t start_done;      // [30:0] row the running episode started on (episode.start_time), [31] episode.done
   double ep_return;        // episode.cumulative_reward
@@ -184,6 +192,9 @@ struct FleetCold {
   int night_hour, night_minute;  // charging_hour / charging_minute; night_hour < 0: not configured
   int night_limit_s;       // 3600 * int(max_time_needed)
   int step_s;              // seconds per table row
+  const int32_t* tab_last_deg;  // [T] the last row <= r that carries FLEET_TFLAG_DEG, -1 before the first one (EnvRec::rf_until)
+  int32_t* last_len;       // [E] length of the env's last finished episode
+  int rf_count_all;        // diagnostics: keep the rainflow count running to the end of every episode (EnvRec::rf_until)
 };
 #define FLEET_NIGHT_IDLE INT32_MIN
 

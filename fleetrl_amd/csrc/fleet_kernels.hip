@@ -733,19 +733,26 @@ __device__ __forceinline__ void reset_ev(const FleetDev& d, int e, int c, int st
 }
 // Start row, finish row and sample count of the env's next episode (time pickers, :351-355) -- every lane of the env computes
 // them for itself (registers, no exchange).
-__device__ __forceinline__ int reset_times(const FleetDev& d, int e, EnvHead& r) {
-  const int start = choose_start(d.cold, d.E, e, r.episodes);
+// `rf_until`: the last row of the new episode on which the degradation model runs (EnvRec::rf_until).
+__device__ __forceinline__ int reset_times(const FleetDev& d, int e, EnvHead& r, int& rf_until) {
+  const FleetCold* cd = d.cold;
+  const int start = choose_start(cd, d.E, e, r.episodes);
   r.t = start;
   r.t_end = d.tab_finish ? d.tab_finish[start] : start + d.episode_steps;  // :355 (exact date match on an irregular grid)
   r.nsamp = (d.deg_mode != FLEET_DEG_NONE) ? 1 : 0;
+  // the degradation model is evaluated on the rows (start, t_end] that carry FLEET_TFLAG_DEG; what is logged after the last of
+  // them is cleared by the next reset() unread
+  const int last = cd->tab_last_deg[r.t_end > d.T - 1 ? d.T - 1 : r.t_end];
+  rf_until = cd->rf_count_all ? INT32_MAX : (last > start ? last : -1);
   return start;
 }
 // The env's part: its record (episode counters zeroed :402-404, the head with the row flags the episode's first step needs).
-__device__ __forceinline__ void reset_head(const FleetDev& d, int e, const EnvHead& r, int start) {
+__device__ __forceinline__ void reset_head(const FleetDev& d, int e, const EnvHead& r, int start, int rf_until) {
   EnvRec* er = d.env + e;
   EnvHead hd = r;
-  hd.nsamp = HEAD_PACK(r.nsamp, d.tab_phys[start].flags_next);
+  hd.nsamp = HEAD_PACK(r.nsamp, d.tab_phys[start].flags_next, start < rf_until);
   er->h = hd;
+  er->rf_until = rf_until;
   er->ep_return = 0.0;
   er->ep_len = 0;
   er->penalty_record = 0.0;
@@ -756,10 +763,11 @@ __device__ __forceinline__ void reset_head(const FleetDev& d, int e, const EnvHe
 
 // `lp`: the env's data-log cursor (rows written so far; only used when the log is on), advanced by the row reset() writes.
 template <int G, bool LOG>
-__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp) {
+__device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool leader, EnvHead& r, float* __restrict__ obs_row, int& lp,
+                                          int& rf_until) {
   const bool log_on = LOG && (d.log_pos != nullptr);
   const int N = d.N;
-  const int start = reset_times(d, e, r);
+  const int start = reset_times(d, e, r, rf_until);
   // data log: the row reset() writes -- time, observation and SoH, zeros for everything else (:420-432)
   const size_t lrow = log_on ? (size_t)(lp % d.log_cap) * d.E + e : 0;
   float* const log_obs_row = log_on ? d.log_obs + lrow * d.obs_dim : nullptr;
@@ -775,7 +783,7 @@ __device__ __forceinline__ void reset_env(const FleetDev& d, int e, int g, bool 
     }
     lp += 1;
   }
-  if (leader) reset_head(d, e, r, start);
+  if (leader) reset_head(d, e, r, start, rf_until);
 }
 
 template <int G>
@@ -789,7 +797,8 @@ __global__ __launch_bounds__(kBlock) void fleet_reset_kernel(FleetDev d, const u
   // an explicit reset of an episode that is in progress abandons it: count it so the next start row differs
   if (d.env[e].ep_len > 0 && d.env[e].start_done >= 0) r.episodes += 1;
   int lp = d.log_pos ? d.log_pos[e] : 0;
-  reset_env<G, true>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp);
+  int rf_until;
+  reset_env<G, true>(d, e, g, g == G - 1, r, obs ? obs + (size_t)e * d.obs_dim : nullptr, lp, rf_until);
   if (d.log_pos && g == G - 1) d.log_pos[e] = lp;
 }
 
@@ -1058,14 +1067,24 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     r.episodes = __builtin_amdgcn_readfirstlane(r.episodes);
   }
   const uint32_t head_flags = HEAD_FLAGS(r.nsamp);  // FLEET_TFLAG_* of row t + 1, left by the previous launch
+  // is the sample this step logs still counted?  (EnvRec::rf_until: nothing reads what is logged after the episode's last
+  // degradation row.)  One step per launch: bit 29 of the head, left by the previous launch's leader, who alone holds the row
+  // itself; K steps per launch: every lane holds the row and compares per step.
+  const bool head_live = HEAD_LIVE(r.nsamp);
   r.nsamp = HEAD_NSAMP(r.nsamp);
   double ep_return = 0.0, penalty_record = 0.0;
   int ep_len = 0;
+  int rf_until = -1;
   if (leader) {
     const EnvRec* er = d.env + e;
     ep_return = er->ep_return;
     penalty_record = er->penalty_record;
     ep_len = er->ep_len;
+    if (DEG == FLEET_DEG_RAINFLOW && !MULTI) rf_until = er->rf_until;
+  }
+  if (DEG == FLEET_DEG_RAINFLOW && MULTI) {
+    rf_until = p_env[e].rf_until;
+    if (G >= 64) rf_until = __builtin_amdgcn_readfirstlane(rf_until);
   }
   uint32_t err = 0;
   double reward_sum = 0.0;
@@ -1120,6 +1139,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     const int t2 = t1 + 1 > d.T - 1 ? d.T - 1 : t1 + 1;  // the row the NEXT step advances to
     const bool is_done = (t + 1 == r.t_end);  // :627-628
     const bool resets = is_done && d.auto_reset;
+    const bool rf_live = MULTI ? (t < rf_until) : head_live;  // the sample of row t + 1 is counted
     // where this step's observation goes: with vec-env auto-reset the terminal observation is reported aside
     float* const step_row = resets ? term_row : obs_row;
     // intermediate steps of a K-step launch only need their observation when the episode ends (terminal observation)
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (kRfCarry) {
         rq.acc = acc_c;
         rq.top = top_c;
-      } else if (kRfEarly && env_ok) {
+      } else if (kRfEarly && env_ok && rf_live) {
         rf_request(d, i, HOT_TAIL(hb.bits), rq);
       }
       double a;
@@ -1287,7 +1307,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       // (K steps per launch: request and consumption stay together -- the registers the request holds across the observation
       // stores would cost the multi-step kernel a resident wavefront per SIMD)
       constexpr bool kSplitRf = !MULTI;
-      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
+      if (kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok && rf_live) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq);
 
       FLEET_STAMP(3);
       // ---- observation of the advanced time row (fleet_environment.py:511-518, 645-652) ------------------------
@@ -1305,7 +1325,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
 
       FLEET_STAMP(4);
       // ---- SOC log + daily degradation (:655-673) -------------------------------------------------------------
-      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
+      if (!kSplitRf && DEG == FLEET_DEG_RAINFLOW && env_ok && rf_live) rf_begin(d, i, old_deg, soc_deg, tail, sgn, rq, kRfEarly);
       ev_finish<DEG, WIDE>(d, i, c, N, env_ok, deg_row, dt_step, rq, tail, sgn, soc, soc_deg, old_deg, hl, tb1.there, t090, inplane,
                            crosses, nr, soh0, a, en, logs, lrow, hb, err, sei_sample, sei_soh, sei_tail, sei_top, sei_have_top, acc_c,
                            top_c, kRfCarry);
@@ -1403,7 +1423,9 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
         const size_t i = ix.flat();
         double deg, soh_new;
         if (!WIDE) {
-          deg = sei_evaluate(*d.self, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
+          // (its scalars from the argument block the end of the step has just re-read, not from the device-resident copy: one
+          // dependent round trip less on the wavefronts that end the launch, -2 % per launch at 4096 x 50)
+          deg = sei_evaluate(d, ix, sei_sample, r.nsamp, sei_tail, sei_top, sei_have_top, err, dt_step,
                              kRfCarry ? &acc_c.rf_len : nullptr);
           soh_new = sei_soh - deg;
         } else {  // several EVs per lane: re-read the few words from the records this lane has just stored
@@ -1429,14 +1451,14 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
       if (leader && env_ok) {
         EnvRec* er = d.env + e;
         er->last_ep_return = ep_return;
-        er->last_ep_len = ep_len;
+        d.cold->last_len[e] = ep_len;
         er->start_done |= (int32_t)0x80000000u;  // episode.done
       }
       r.episodes += 1;
       if (resets) {
         head_reset = true;
         if (env_ok) {
-          reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp);
+          reset_env<G, LOG>(*d.self, e, g, leader, r, obs_row, lp, rf_until);
           if (kRfCarry) carry_load();  // the reset rewrote the row's head (same lane, same addresses: program order holds)
         } else {  // surplus group: keep its registers moving without touching memory
           r.t = choose_start(d.cold, d.E, e, r.episodes);
@@ -1471,7 +1493,7 @@ __global__ __launch_bounds__(kBlock, MULTI ? (WIDE ? kMultiWideWaves : kMultiWav
     // the head carries the row flags the next launch's state machine needs (struct EnvHead)
     uint32_t nflags = head_after;
     if (!kEarly || head_reset) nflags = d.tab_phys[r.t].flags_next;
-    r.nsamp = HEAD_PACK(r.nsamp, nflags);
+    r.nsamp = HEAD_PACK(r.nsamp, nflags, r.t < rf_until);
     er->h = r;
     er->ep_return = ep_return;
     er->ep_len = ep_len;
@@ -1573,8 +1595,9 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
     case FLEET_F_EP_RETURN: ((double*)out)[i] = d.env[i].ep_return; break;
     case FLEET_F_EP_LEN: ((int32_t*)out)[i] = d.env[i].ep_len; break;
     case FLEET_F_LAST_EP_RETURN: ((double*)out)[i] = d.env[i].last_ep_return; break;
-    case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.env[i].last_ep_len; break;
-    case FLEET_F_LAST_EP_LEN_F64: ((double*)out)[i] = (double)d.env[i].last_ep_len; break;
+    case FLEET_F_LAST_EP_LEN: ((int32_t*)out)[i] = d.cold->last_len[i]; break;
+    case FLEET_F_LAST_EP_LEN_F64: ((double*)out)[i] = (double)d.cold->last_len[i]; break;
+    case FLEET_F_RF_UNTIL: ((int32_t*)out)[i] = d.env[i].rf_until; break;
     case FLEET_F_ERROR_BITS: ((uint32_t*)out)[i] = d.env[i].err; break;
     case FLEET_F_DONE: ((uint8_t*)out)[i] = (uint8_t)(d.env[i].start_done < 0); break;
     case FLEET_F_EPISODES: ((int32_t*)out)[i] = d.env[i].h.episodes; break;
@@ -1588,7 +1611,8 @@ __global__ void fleet_gather_field_kernel(FleetDev d, int field, void* __restric
 // env order (deterministic), then the rows are copied by the whole launch.
 __global__ __launch_bounds__(1024) void fleet_term_scan_kernel(const uint8_t* __restrict__ done, int E, int32_t* __restrict__ idx,
                                                                int32_t* __restrict__ count, const EnvRec* __restrict__ env,
-                                                               double* __restrict__ ep_ret, int32_t* __restrict__ ep_len) {
+                                                               const FleetCold* __restrict__ cold, double* __restrict__ ep_ret,
+                                                               int32_t* __restrict__ ep_len) {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1606,7 +1630,7 @@ __global__ __launch_bounds__(1024) void fleet_term_scan_kernel(const uint8_t* __
     if (f) {  // the finished episode's return / length travel with the index (what SB3's Monitor would report)
       idx[off + before] = e;
       ep_ret[off + before] = env[e].last_ep_return;
-      ep_len[off + before] = env[e].last_ep_len;
+      ep_len[off + before] = cold->last_len[e];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1859,7 +1883,7 @@ hipError_t fleet_describe_step(const FleetDev& d, const void* actions, int act_d
 
 hipError_t fleet_launch_term_compact(const FleetDev& d, const uint8_t* done, const float* term, int32_t* idx, int32_t* count,
                                      double* ep_ret, int32_t* ep_len, float* compact, hipStream_t s) {
-  hipLaunchKernelGGL(fleet_term_scan_kernel, dim3(1), dim3(1024), 0, s, done, d.E, idx, count, d.env, ep_ret, ep_len);
+  hipLaunchKernelGGL(fleet_term_scan_kernel, dim3(1), dim3(1024), 0, s, done, d.E, idx, count, d.env, d.cold, ep_ret, ep_len);
   hipLaunchKernelGGL(fleet_term_gather_kernel, dim3(256), dim3(256), 0, s, term, d.obs_dim, idx, count, compact);
   return hipGetLastError();
 }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLEET_ABI_VERSION 9
+#define FLEET_ABI_VERSION 10
 
 /* status codes */
 #define FLEET_OK 0
@@ -210,6 +210,9 @@ typedef struct FleetEnvBatch* fleet_handle;
 #define FLEET_F_RF_CYCLES 21     /* i32 [E,N] rainflow cycles closed so far in the running episode (0 without rainflow degradation) */
 #define FLEET_F_RF_STACK 22      /* i32 [E,N] reversal points on the EV's rainflow stack (bench.py derives the share of EV-steps that
                                     push a reversal point / close a cycle from the two: the workload's invariants)               */
+#define FLEET_F_RF_UNTIL 23      /* i32 [E]   the last table row of the running episode on which the degradation model is evaluated
+                                    (-1: none; INT32_MAX after fleet_set_rainflow_count_all): SOC samples logged after it are not
+                                    counted, see fleet_set_rainflow_count_all                                                   */
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */
 int fleet_obs_dim(const FleetParams* p);  /* detect_dim_and_bounds, fleet_environment.py:854-949; <0 on invalid flags */
@@ -253,6 +256,15 @@ int fleet_rollout_policy_dev(fleet_handle h, int policy, int K, float* obs, doub
  * distributed rule instead.  Each env keeps its own "charging since" state, which -- like the reference's loop
  * variable -- survives episode resets; this call clears it.  Not callable while a captured graph is replaying. */
 int fleet_set_night_policy(fleet_handle h, int charging_hour, int charging_minute, int max_hours);
+/* The rainflow count stops at the episode's last degradation row.  The reference appends one SOC sample per EV and step to
+ * LogDataDeg (fleet_environment.py:655) and runs rainflow.extract_cycles on that log only on the 14:45 rows (:665,
+ * rainflow_sei_degradation.py:132); reset() clears the log (:338-339).  What is logged between an episode's last 14:45 row and
+ * its end is therefore never read by anybody -- with 48 h episodes a quarter of all samples -- and the kernels, which count
+ * while they log, stop counting there (FLEET_F_RF_UNTIL; state of health, fd_cyc, rainflow_length, observations, rewards:
+ * exactly as with the full count, tests/test_rf_tail_gpu.py).  `on` != 0 keeps the count running to the end of every episode
+ * from each env's next reset on (FLEET_F_RF_CYCLES / FLEET_F_RF_STACK then describe the whole series: diagnostics, the
+ * adversarial count tests).  Default: off.  Not callable while a captured graph is replaying. */
+int fleet_set_rainflow_count_all(fleet_handle h, int on);
 
 /* ---- reset / step, host pointers, synchronous ------------------------------------------------------------ */
 int fleet_reset_host(fleet_handle h, const uint8_t* mask, float* obs);

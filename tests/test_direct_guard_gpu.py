@@ -221,6 +221,7 @@ def test_rainflow_cycle_and_stack_getters_count_what_a_plain_rainflow_counts():
     """FLEET_F_RF_CYCLES / FLEET_F_RF_STACK (bench.py's workload invariants: the share of EV-steps that push a reversal point / close a
     cycle) against a plain three-point rainflow over the logged SOC samples of every EV, inside one episode."""
     g, (b,), rng = _batch(E=6)
+    b.set_rainflow_count_all(True)  # (by default the count stops at the episode's last degradation row: tests/test_rf_tail_gpu.py)
     obs = b.reset()
     series = [b.get("soc_deg").copy()]
     ep0 = b.get("episodes").copy()

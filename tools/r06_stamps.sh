@@ -12,7 +12,7 @@ for f in ab_stamps/*.so; do
     for D in ${DEGS:-rainflow}; do
     for LAUNCH in ${LAUNCHES:-0 2}; do  # 0: hipLaunchKernel per step, 2: the library's own queue
       echo "==== $(basename $f .so) E=$E deg $D launch mode $LAUNCH" >> gpurun_out/r06/${TAG}_stamps.log
-      DEG=$D LAUNCH=$LAUNCH E=$E STEPS=20011 timeout 300 python3 tools/stamps.py 2>&1 | grep -v amdgpu.ids | head -30 >> gpurun_out/r06/${TAG}_stamps.log
+      DEG=$D LAUNCH=$LAUNCH E=$E STEPS=${STEPS:-20011} timeout 300 python3 tools/stamps.py 2>&1 | grep -v amdgpu.ids | head -30 >> gpurun_out/r06/${TAG}_stamps.log
     done
     done
   done

@@ -76,6 +76,8 @@ if sel.any():
         g = f[lds]
         seg.update({"copy into the LDS": g[:, 14] - g[:, 11], "count of the pending points": g[:, 15] - g[:, 14],
                     "forced point + residuals": g[:, 12] - g[:, 15]})
+    if not lds.any():
+        seg["stack walk + cycle stresses"] = f[:, 12] - f[:, 11]
     seg.update({"SEI model (3 exp)": f[:, 13] - f[:, 12], "write-back -> exit": f[:, 8] - f[:, 13]})
     print(f"daily pass, {int(sel.sum())} wavefronts ({int(lds.sum())} through the LDS):",
           {k: (int(np.median(v)), int(np.percentile(v, 90)), int(v.max())) for k, v in seg.items()}, "(median, p90, max cycles)")
