@@ -15,3 +15,4 @@ timeout 300 python3 bench.py --envs-per-gpu 16384 --no-cpu-baseline --no-host-pa
 for f in default default_20steps c5 16384x50; do python3 -c "
 import json; d=json.loads(open('$OUT/r06_bench_$f.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$f', 'ms/step %.4f'%d['ms_per_step'], 'kernel_ms %.4f frac %.3f'%(r['kernel_ms'],r['frac']), 'traffic', r['traffic'], 'many %.3e'%d['step_many']['env_steps_per_s'])"; done
 cat gpurun_out/r06/gpu_tests.txt; head -3 gpurun_out/r06/obs_words_identical.txt
+bash tools/launch_by_episode_step.sh > /dev/null 2>&1; cp gpurun_out/r06/launch_by_episode_step.log $OUT/launch_by_episode_step.log; head -3 $OUT/launch_by_episode_step.log
